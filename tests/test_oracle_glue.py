@@ -1,0 +1,73 @@
+"""CPU oracle (oracle/rsgm_oracle.c, vpp_oracle.c) vs golden vectors produced by importing the
+reference's Python glue (tests/golden/make_glue_golden.py): rsgm.py, filter.py,
+vpp_standalone.py, losses.py."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(GOLDEN, "glue_cases.npz"))
+
+
+def test_linear_interpolate(G):  # rsgm.py:67-113
+    for i in range(3):
+        a = G[f"linint{i}_in"].copy()
+        oracle._linear_interpolate(a, 15, 3)
+        assert np.array_equal(a, G[f"linint{i}_out"]), i
+        assert not np.array_equal(a, G[f"linint{i}_in"])
+
+
+def test_left_right_check(G):  # rsgm.py:230-248
+    for i in range(2):
+        m = oracle._left_right_check(G[f"lrc{i}_dl"], G[f"lrc{i}_dr"], 1)
+        assert np.array_equal(m, G[f"lrc{i}_mask"]), i
+        assert set(np.unique(m)) == {0, 128, 255}
+
+
+def test_interpolate_background(G):  # rsgm.py:185-227
+    for i in range(3):
+        a = G[f"bg{i}_in"].copy()
+        oracle._interpolate_background(a)
+        assert np.array_equal(a, G[f"bg{i}_out"]), i
+
+
+def test_occlusion_heuristic_conf(G):  # filter.py:246-292 (conf map = g_occ of test.py:154)
+    for i in range(2):
+        _, conf = oracle.occlusion_heuristic(G[f"occ{i}_in"])
+        assert np.array_equal(conf, G[f"occ{i}_conf"]), i
+        hints = G[f"occ{i}_in"] > 0
+        assert 0 < (conf[hints] == 0).sum() < hints.sum()  # some hints kept, some flagged
+
+
+def test_bilateral_filling(G):  # vpp_standalone.py:372-394
+    for i in range(2):
+        out = oracle.bilateral_filling(G[f"bil{i}_dmap"], G[f"bil{i}_img"], int(G[f"bil{i}_n"]), 2, 1, .001)
+        assert np.array_equal(out, G[f"bil{i}_out"]), i
+
+
+def test_patch_size_based_on_distance(G):  # vpp_standalone.py:7-11
+    got = [oracle.patch_radius(float(d), 1.0, 50.0, 7, 0.3) for d in G["patch_d"]]
+    assert got == G["patch_n"].tolist()
+    assert set(got) == {0, 1, 2, 3}
+
+
+def test_vpp_wrapper_structure(G):  # vpp_standalone.py:396-432
+    left, right = G["vppw_left"], G["vppw_right"]
+    lc, rc = oracle.vpp(left, right, np.zeros(left.shape[:2], np.float64))
+    assert np.array_equal(lc, G["vppw_lc0"]) and np.array_equal(rc, G["vppw_rc0"])
+    assert lc is not left
+    lcg, _ = oracle.vpp(left[..., 0], right[..., 0], np.zeros(left.shape[:2], np.float32))
+    assert list(lcg.shape) == G["vppw_lcg_shape"].tolist()
+
+
+def test_guided_metrics(G):  # losses.py:13-24
+    m = oracle.guided_metrics(G["gm_disp"], G["gm_gt"], G["gm_valid"])
+    got = np.asarray([m['bad 1.0'], m['bad 2.0'], m['bad 3.0'], m['bad 4.0'], m['avgerr'], m['rms']])
+    assert np.allclose(got, G["gm_out"], rtol=1e-6, atol=1e-7)
