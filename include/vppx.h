@@ -1,0 +1,201 @@
+/*
+ * vppx.h -- C-ABI of libvppx.so: MI355X-native (gfx950) virtual-pattern-projection +
+ * rSGM hot path.  Drop-in boundary for the reference's native entry points:
+ *
+ *   reference native (file:line)                                   replaced by
+ *   ------------------------------------------------------------   ---------------------------
+ *   vpp_core_opt.init_rand              vpp_core_opt.pyx:33-35      vppx_srand
+ *   vpp_core_opt.virtual_projection_scan_rnd       .pyx:53-54       vppx_virtual_projection_scan_rnd
+ *   vpp_core_opt.virtual_projection_scan_max_dist  .pyx:133-134     vppx_virtual_projection_scan_max_dist
+ *   numba twins + wrapper vpp()         vpp_standalone.py:243,14,396 vppx_vpp_host / vppx_vpp_dev
+ *   pyrSGM.census5x5_SSE                call site rsgm.py:25        vppx_census5x5
+ *   pyrSGM.costMeasureCensus5x5_xyd_SSE call site rsgm.py:44        vppx_cost_census5x5_xyd
+ *   pyrSGM.aggregate_SSE                call site rsgm.py:61        vppx_aggregate
+ *   pyrSGM.matchWTA_SSE                 call site rsgm.py:141       vppx_match_wta
+ *   pyrSGM.subPixelRefine               call site rsgm.py:142       vppx_subpixel_refine
+ *   pyrSGM.median3x3_SSE                call site rsgm.py:145,173   vppx_median3x3
+ *   pyrSGM.matchWTARight_SSE            call site rsgm.py:170       vppx_match_wta_right
+ *   compute_rsgm()                      rsgm.py:250-294             vppx_rsgm_host / vppx_rsgm_dev
+ *   occlusion_heuristic()               filter.py:246-292           vppx_occlusion_heuristic_host/_dev
+ *   test.py:158-225 (VPP -> rSGM per frame)                         vppx_vpp_rsgm_dev (fused, batched)
+ *
+ * Conventions
+ *   - plain C, no torch types.  "_host" entry points take host pointers (what a ctypes /
+ *     numpy caller has) and are synchronous; "_dev" entry points take device pointers,
+ *     enqueue on the context's HIP stream and return without synchronising.
+ *   - images are uint8, HWC, C-contiguous, batch outermost: [B,H,W,C]; hint / disparity
+ *     maps are float32 [B,H,W]; masks uint8 [B,H,W].  Exactly the reference's layouts
+ *     (vpp_core_opt.pyx:53, rsgm.py:42,60) with a leading batch dimension.
+ *   - every function returns 0 on success or a negative VPPX_E_* code; the message of
+ *     the last error on the calling thread is available from vppx_last_error().  Codes map
+ *     one-to-one onto the reference's Python exceptions (rsgm.py:19-20,31-40,157-167).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     VPPX_E_NO_DEVICE.
+ */
+#ifndef VPPX_H
+#define VPPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPPX_VERSION 100
+
+enum {
+    VPPX_OK = 0,
+    VPPX_E_INVALID_ARG = -1,     /* null pointer, bad shape, bad enum                       */
+    VPPX_E_DMAX_MOD8 = -2,       /* "Invalid dmax (..): dmax % 8 != 0"      rsgm.py:31-32   */
+    VPPX_E_DMAX_GT256 = -3,      /* "Invalid dmax (..): dmax > 256"         rsgm.py:34-35   */
+    VPPX_E_UNIQUENESS = -4,      /* "Invalid uniqueness (..) in ]0,1]"      rsgm.py:166-167 */
+    VPPX_E_WIDTH_MOD16 = -5,     /* "Invalid width (..): width % 16 != 0"   rsgm.py:19-20   */
+    VPPX_E_METHOD = -6,          /* assert method in ["rnd","maxDistance"]  vpp_standalone.py:400 */
+    VPPX_E_NO_DEVICE = -7,       /* no HIP device / HIP runtime error at init               */
+    VPPX_E_HIP = -8,             /* HIP runtime error (message has the hipError string)     */
+    VPPX_E_OOM = -9,             /* workspace allocation failed                             */
+    VPPX_E_UNSUPPORTED = -10     /* valid in the reference but outside this build's limits  */
+};
+
+enum { VPPX_METHOD_RND = 0, VPPX_METHOD_MAXDIST = 1 };
+
+/* Parameters of the VPP scans.  Field meaning = the same-named argument of
+ * vpp_core_opt.pyx:53-54 / :133-134 and vpp_standalone.py:396 (defaults in brackets). */
+typedef struct VppxVppParams {
+    int32_t method;             /* VPPX_METHOD_*                 ["rnd"]                    */
+    int32_t wsize;              /* patch size 2n+1               [3]                        */
+    int32_t wsize_agg_x;        /* maxDistance window            [64]                       */
+    int32_t wsize_agg_y;        /*                               [3]                        */
+    int32_t direction;          /* 1 = left2right scan, 0 = r2l  [1]                        */
+    int32_t uniform_color;      /*                               [0]                        */
+    int32_t discard_occluded;   /*                               [0]                        */
+    int32_t interpolate;        /*                               [1]                        */
+    float c;                    /* blending                      [0.4]                      */
+    float c_occ;                /*                               [0.0]                      */
+    /* numba-twin extras (vpp_standalone.py:93-96,154,315-318,335) */
+    int32_t use_distance_patch; /*                               [0]                        */
+    int32_t use_bilateral_patch;/* gate on |g - filled_g| < 0.1  [0] (needs filled_g)       */
+    double distance_gamma;      /*                               [0.3]                      */
+    float dmin, dmax;           /* min / max positive hint of the frame (wrapper :410-411)  */
+    /* random stream (libc rand() in the reference, vpp_core_opt.pyx:33-35,93,102):
+     * frame f of a batch draws from srand(seed + f) starting rand_offset draws in.        */
+    uint32_t seed;              /*                               [1]                        */
+    uint32_t reserved0;
+    uint64_t rand_offset;       /*                               [0]                        */
+} VppxVppParams;
+
+/* Parameters of compute_rsgm (rsgm.py:250). */
+typedef struct VppxRsgmParams {
+    int32_t dmax;        /* [192]  multiple of 8, <= 256 */
+    int32_t p1;          /* [11]   */
+    int32_t p2min;       /* [17]   */
+    float alpha;         /* [0.5]  */
+    int32_t gamma;       /* [35]   */
+    float uniqueness;    /* [0.95] */
+    int32_t subpixel;    /* [1]  (test.py:71 passes False) */
+    int32_t reserved0;
+} VppxRsgmParams;
+
+typedef struct vppx_ctx vppx_ctx; /* opaque: device, stream, workspace arena */
+
+/* ---- library / context ------------------------------------------------------------ */
+int vppx_version(void);
+const char *vppx_last_error(void);
+void vppx_vpp_params_default(VppxVppParams *p);
+void vppx_rsgm_params_default(VppxRsgmParams *p);
+
+/* Create a context on HIP device `device` (-1 = current device).  One context per
+ * process/GPU; not thread-safe (the reference is single-threaded: rsgm.py:44). */
+int vppx_create(vppx_ctx **out, int device);
+void vppx_destroy(vppx_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+int vppx_set_stream(vppx_ctx *ctx, void *hip_stream);
+int vppx_synchronize(vppx_ctx *ctx);
+/* Bytes of device workspace currently held by the context. */
+size_t vppx_workspace_bytes(const vppx_ctx *ctx);
+/* Name of the HIP device the context runs on (e.g. "AMD Instinct MI355X"). */
+const char *vppx_device_name(const vppx_ctx *ctx);
+
+/* ---- libc-style random stream of the single-frame scans ----------------------------- */
+/* init_rand(seed) (vpp_core_opt.pyx:33): restart the context's stream; subsequent
+ * vppx_virtual_projection_scan_* calls continue it exactly like libc's global state. */
+int vppx_srand(vppx_ctx *ctx, uint32_t seed);
+/* Device-generated glibc rand() stream: out[i] = i-th rand() after srand(seed), for
+ * i in [offset, offset+n).  Host pointer. */
+int vppx_rand_stream(vppx_ctx *ctx, uint32_t seed, uint64_t offset, int64_t n, int32_t *out);
+
+/* ---- VPP: reference native signatures (host pointers, in place, single frame) -------- */
+/* vpp_core_opt.pyx:53-54.  Returns the number of hints (>= 0) or a negative error. */
+int vppx_virtual_projection_scan_rnd(vppx_ctx *ctx, uint8_t *l, uint8_t *r, const float *g, int width, int height,
+                                     int channels, int uniform_color, int wsize, int direction, float c,
+                                     float c_occ, const uint8_t *g_occ, int discard_occluded, int interpolate);
+/* vpp_core_opt.pyx:133-134. */
+int vppx_virtual_projection_scan_max_dist(vppx_ctx *ctx, uint8_t *l, uint8_t *r, const float *g, int width,
+                                          int height, int channels, int uniform_color, int wsize, int wsize_agg_x,
+                                          int wsize_agg_y, int direction, float c, float c_occ,
+                                          const uint8_t *g_occ, int discard_occluded, int interpolate);
+
+/* ---- VPP: batched form ---------------------------------------------------------------- */
+/* l, r are updated in place; g_occ / filled_g may be NULL; n_hints (host, [B]) may be NULL
+ * for the _dev form (then nothing is copied back). */
+int vppx_vpp_host(vppx_ctx *ctx, const VppxVppParams *p, int B, int H, int W, int C, uint8_t *l, uint8_t *r,
+                  const float *g, const uint8_t *g_occ, const float *filled_g, int64_t *n_hints);
+int vppx_vpp_dev(vppx_ctx *ctx, const VppxVppParams *p, int B, int H, int W, int C, uint8_t *l, uint8_t *r,
+                 const float *g, const uint8_t *g_occ, const float *filled_g, int64_t *n_hints_dev);
+
+/* Number of rand() draws each frame of the last vppx_vpp_* call consumed (host array [B]);
+ * synchronises the stream.  Lets a caller continue the libc-like stream across calls. */
+int vppx_vpp_last_draws(vppx_ctx *ctx, int B, uint64_t *draws);
+
+/* ---- rSGM: pyrSGM-compatible stage entry points (host pointers, single frame) ---------- */
+int vppx_census5x5(vppx_ctx *ctx, const uint8_t *img, uint32_t *out, int w, int h);
+int vppx_cost_census5x5_xyd(vppx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, uint16_t *dsi, int w, int h,
+                            int dmax, int n_threads_ignored);
+int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t *dsi, uint16_t *dsi_agg, int w, int h,
+                   int dmax, int p1, int p2min, float alpha, int gamma);
+int vppx_match_wta(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, float uniqueness);
+int vppx_match_wta_right(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax,
+                         float uniqueness);
+int vppx_subpixel_refine(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, int method);
+int vppx_median3x3(vppx_ctx *ctx, const float *src, float *dst, int w, int h);
+
+/* ---- rSGM: whole compute_rsgm (rsgm.py:250-294), batched -------------------------------- */
+/* left / left_vpp / right_vpp: uint8 [B,H,W,C] (C = 1 or 3); disp_out: float32 [B,H,W].
+ * hints / validhints: reserved for --guided (must be NULL in this build). */
+int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,
+                   const uint8_t *left_vpp, const uint8_t *right_vpp, const float *hints, const float *validhints,
+                   float *disp_out);
+int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,
+                  const uint8_t *left_vpp, const uint8_t *right_vpp, const float *hints, const float *validhints,
+                  float *disp_out);
+
+/* ---- fused hot path: VPP (in place on copies) + rSGM, batched, device pointers ----------- */
+/* left/right: original pair uint8 [B,H,W,C] (not modified); l_vpp/r_vpp: outputs, patterned
+ * pair (may be NULL -> internal scratch); disp_out float32 [B,H,W]. */
+int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W, int C,
+                      const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                      uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out);
+
+/* ---- occlusion heuristic (filter.py:246-292): hints -> g_occ mask ------------------------- */
+int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l,
+                                  double g, double th_conf, double th_filter, uint8_t *conf_out);
+int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l,
+                                 double g, double th_conf, double th_filter, uint8_t *conf_out);
+
+/* ---- measurement helpers (bench.py) ------------------------------------------------------- */
+/* Time `iters` back-to-back launches of the dominant kernel (8-path aggregation) on the
+ * context's stream with hipEvents around the kernel only; returns average ms per launch
+ * in *ms_out.  Operates on the workspace state left by the last vppx_rsgm_dev call. */
+int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out);
+/* Per-stage hipEvent timing of the last vppx_vpp_rsgm_dev/vppx_rsgm_dev call when stage
+ * timing is enabled: fills ms[0..n) and returns the number of stages; names via
+ * vppx_stage_name(i). */
+int vppx_enable_stage_timing(vppx_ctx *ctx, int enable);
+int vppx_get_stage_ms(vppx_ctx *ctx, float *ms, int max_n);
+const char *vppx_stage_name(int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPPX_H */

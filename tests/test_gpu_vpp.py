@@ -1,0 +1,191 @@
+"""GPU parity, VPP: the HIP path (through the C-ABI, via the drop-in modules) against
+ (1) the committed golden vectors of the reference's Cython build, and
+ (2) the CPU oracle on fresh seeded inputs, bit-exact (uint8 pattern grid)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from test_oracle_vpp import _anchor_inputs, run_case
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from vppstereo_amd import vpp_core_opt
+    return vpp_core_opt
+
+
+def test_device_glibc_rand_stream_matches_fixture_and_libc():
+    from vppstereo_amd import _lib
+    lib, ctx = _lib.load(), _lib.default_context()
+    with open(os.path.join(GOLDEN, "glibc_rand.json")) as f:
+        fix = json.load(f)
+    for seed, vals in fix.items():
+        out = np.empty(len(vals), np.int32)
+        _lib.check(lib.vppx_rand_stream(ctx.handle, int(seed), 0, len(vals), _lib.np_ptr(out)))
+        assert out.tolist() == vals, f"seed {seed}"
+    libc = C.CDLL("libc.so.6")
+    libc.rand.restype = C.c_int
+    libc.srand(C.c_uint(77))
+    want = [libc.rand() for _ in range(5000)]
+    for off, n in ((0, 5000), (1, 100), (991, 2000), (992, 993), (4000, 1000)):
+        out = np.empty(n, np.int32)
+        _lib.check(lib.vppx_rand_stream(ctx.handle, 77, off, n, _lib.np_ptr(out)))
+        assert out.tolist() == want[off:off + n], (off, n)
+    # far jump-ahead vs the oracle's sequential generator
+    big = oracle.rand_stream(5, 3_000_000)
+    out = np.empty(4096, np.int32)
+    _lib.check(lib.vppx_rand_stream(ctx.handle, 5, 3_000_000 - 4096, 4096, _lib.np_ptr(out)))
+    assert np.array_equal(out, big[-4096:])
+
+
+def test_rnd_golden_cases_bit_exact(gpu):
+    store = np.load(os.path.join(GOLDEN, "vpp_cases.npz"))
+    with open(os.path.join(GOLDEN, "vpp_cases.json")) as f:
+        cases = [c for c in json.load(f) if c["method"] == "rnd"]
+    assert len(cases) > 50
+    bad = []
+    for case in cases:
+        n, l, r = run_case(gpu, case, store)
+        ok = n == case["n_hints"] and np.array_equal(l, store[case["name"] + "_l"]) and \
+            np.array_equal(r, store[case["name"] + "_r"])
+        if not ok:
+            bad.append((case["name"], {k: case[k] for k in ("inp", "uniform", "direction", "interpolate", "discard",
+                                                           "c_occ", "wsize", "use_occ")},
+                        int((l != store[case["name"] + "_l"]).sum()), int((r != store[case["name"] + "_r"]).sum())))
+    assert not bad, bad[:8]
+
+
+def test_rnd_full_size_anchor_hashes(gpu):
+    """540x960x3, 3 % hints: SHA-256 of the reference's outputs."""
+    with open(os.path.join(GOLDEN, "vpp_anchors.json")) as f:
+        meta = json.load(f)
+    l, r, g, occ0, occ1 = _anchor_inputs(meta)
+    if _sha(l) != meta["inputs"]["l"] or _sha(g) != meta["inputs"]["g"]:
+        pytest.skip("numpy Generator stream differs from the one the anchors were made with")
+    H, W = meta["H"], meta["W"]
+    by = {c["name"]: c for c in meta["cases"]}
+    for name, occ, args, seed in (("rnd_occ0", occ0, (False, 3, 1, 0.4, 0.0), 1), ("rnd_occ1", occ1, (False, 3, 1, 0.4, 0.0), 1),
+                                  ("rnd_w7_uniform_r2l_cocc", occ1, (True, 7, 0, 0.4, 0.25), 3)):
+        a, b = l.copy(), r.copy()
+        gpu.init_rand(seed)
+        n = gpu.virtual_projection_scan_rnd(a, b, g, W, H, 3, args[0], args[1], args[2], args[3], args[4], occ, False, True)
+        assert n == by[name]["n_hints"]
+        assert _sha(a) == by[name]["l"], name
+        assert _sha(b) == by[name]["r"], name
+
+
+@pytest.mark.parametrize("H,W,C,p,dmax", [(37, 53, 3, 0.07, 20.0), (64, 300, 1, 0.03, 190.0), (5, 7, 3, 0.5, 4.0),
+                                          (120, 260, 3, 0.25, 60.0)])
+def test_rnd_vs_oracle_random_inputs(gpu, H, W, C, p, dmax):
+    rng = np.random.default_rng(H * 1000 + W)
+    for trial in range(6):
+        l = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+        r = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+        g = np.where(rng.random((H, W)) < p, rng.uniform(0.05, dmax, (H, W)), 0).astype(np.float32)
+        g[rng.random((H, W)) < p / 4] = np.float32(rng.integers(1, 9))
+        occ = (rng.random((H, W)) < 0.3).astype(np.uint8)
+        uniform, direction, interp, discard = [bool(b) for b in rng.integers(0, 2, 4)]
+        wsize = int(rng.choice([1, 3, 5, 7, 9]))
+        c, c_occ = float(np.float32(rng.uniform(0.05, 0.95))), float(np.float32(rng.choice([0.0, 0.2, 0.7])))
+        seed = int(rng.integers(0, 2**31))
+        a0, b0 = l.copy(), r.copy()
+        oracle.init_rand(seed)
+        n0 = oracle.virtual_projection_scan_rnd(a0, b0, g, W, H, C, uniform, wsize, direction, c, c_occ, occ, discard, interp)
+        a1, b1 = l.copy(), r.copy()
+        gpu.init_rand(seed)
+        n1 = gpu.virtual_projection_scan_rnd(a1, b1, g, W, H, C, uniform, wsize, direction, c, c_occ, occ, discard, interp)
+        cfg = dict(uniform=uniform, direction=direction, interp=interp, discard=discard, wsize=wsize, c=c, c_occ=c_occ)
+        assert n0 == n1, cfg
+        assert np.array_equal(a0, a1), (cfg, int((a0 != a1).sum()))
+        assert np.array_equal(b0, b1), (cfg, int((b0 != b1).sum()))
+
+
+def test_stream_continues_across_scans_like_libc(gpu):
+    """Two scans after one init_rand consume one continuous glibc stream (global libc state
+    in the reference)."""
+    rng = np.random.default_rng(9)
+    H, W = 30, 40
+    l = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    r = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    g = np.where(rng.random((H, W)) < 0.1, rng.uniform(1, 12, (H, W)), 0).astype(np.float32)
+    occ = np.zeros((H, W), np.uint8)
+    a0, b0, a1, b1 = l.copy(), r.copy(), l.copy(), r.copy()
+    oracle.init_rand(11)
+    gpu.init_rand(11)
+    for _ in range(2):
+        oracle.virtual_projection_scan_rnd(a0, b0, g, W, H, 3, False, 3, 1, 0.4, 0.0, occ, False, True)
+        gpu.virtual_projection_scan_rnd(a1, b1, g, W, H, 3, False, 3, 1, 0.4, 0.0, occ, False, True)
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+
+
+def test_vpp_wrapper_matches_oracle_wrapper():
+    """vpp() drop-in (vpp_standalone.py:396) incl. g_occ from the occlusion heuristic and the
+    distance-patch option."""
+    from vppstereo_amd import vpp_standalone, filter as vfilter
+    fr = synth.make_frame(96, 160, 48, 0.05, seed=5)
+    _, conf_o = oracle.occlusion_heuristic(fr["hints"])
+    _, conf_g = vfilter.occlusion_heuristic(fr["hints"])
+    assert np.array_equal(conf_o, conf_g)
+    for kw in (dict(), dict(g_occ=conf_o, c_occ=0.1), dict(wsize=5, uniform_color=True, left2right=False),
+               dict(wsize=7, use_distance_patch=True, g_occ=conf_o)):
+        oracle.init_rand(4)
+        lo, ro = oracle.vpp(fr["left"], fr["right"], fr["hints"], **kw)
+        vpp_standalone.init_rand(4)
+        lg, rg = vpp_standalone.vpp(fr["left"], fr["right"], fr["hints"], **kw)
+        assert lg.dtype == np.uint8 and lg.shape == lo.shape
+        assert np.array_equal(lo, lg) and np.array_equal(ro, rg), kw
+    # gray input -> [H,W,1]
+    oracle.init_rand(4)
+    lo, ro = oracle.vpp(fr["left"][..., 0], fr["right"][..., 0], fr["hints"])
+    vpp_standalone.init_rand(4)
+    lg, rg = vpp_standalone.vpp(fr["left"][..., 0], fr["right"][..., 0], fr["hints"])
+    assert lg.shape == (96, 160, 1) and np.array_equal(lo, lg) and np.array_equal(ro, rg)
+
+
+def test_occlusion_heuristic_golden():
+    from vppstereo_amd import filter as vfilter
+    G = np.load(os.path.join(GOLDEN, "glue_cases.npz"))
+    for i in range(2):
+        _, conf = vfilter.occlusion_heuristic(G[f"occ{i}_in"])
+        assert np.array_equal(conf, G[f"occ{i}_conf"]), i
+
+
+def test_batched_vpp_is_sharding_independent():
+    """Frame f of a batch uses srand(seed+f): the same frames give the same result whatever the
+    batch split (what makes frame sharding across GPUs exact)."""
+    from vppstereo_amd import _lib
+    lib, ctx = _lib.load(), _lib.default_context()
+    b = synth.make_batch(5, 40, 64, 24, 0.06, seed=77)
+
+    def run(lo, hi, seed0):
+        l = np.ascontiguousarray(b["left"][lo:hi]).copy()
+        r = np.ascontiguousarray(b["right"][lo:hi]).copy()
+        g = np.ascontiguousarray(b["hints"][lo:hi])
+        p = _lib.vpp_params(seed=seed0 + lo)
+        nh = (C.c_int64 * (hi - lo))()
+        _lib.check(lib.vppx_vpp_host(ctx.handle, C.byref(p), hi - lo, 40, 64, 3, _lib.np_ptr(l), _lib.np_ptr(r),
+                                     _lib.np_ptr(g), None, None, nh))
+        return l, r, list(nh)
+    l_all, r_all, nh = run(0, 5, 1000)
+    l_a, r_a, _ = run(0, 2, 1000)
+    l_b, r_b, _ = run(2, 5, 1000)
+    assert np.array_equal(l_all, np.concatenate([l_a, l_b])) and np.array_equal(r_all, np.concatenate([r_a, r_b]))
+    for f in range(5):
+        a0, b0 = b["left"][f].copy(), b["right"][f].copy()
+        oracle.init_rand(1000 + f)
+        n = oracle.virtual_projection_scan_rnd(a0, b0, b["hints"][f], 64, 40, 3, False, 3, 1, 0.4, 0.0,
+                                               np.zeros((40, 64), np.uint8), False, True)
+        assert n == nh[f] and np.array_equal(a0, l_all[f]) and np.array_equal(b0, r_all[f])

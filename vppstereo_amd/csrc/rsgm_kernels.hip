@@ -1,0 +1,1008 @@
+// rsgm_kernels.hip -- rSGM back-end on gfx950 (CDNA4), hand-written HIP.
+//
+// Replaces, for the hot path only, the pyrSGM natives called from the reference's
+// models/rsgm/rsgm.py (:25,26 census5x5_SSE; :44 costMeasureCensus5x5_xyd_SSE; :61
+// aggregate_SSE; :141 matchWTA_SSE; :142 subPixelRefine; :145,173 median3x3_SSE; :170
+// matchWTARight_SSE) and the numba/cv2 glue of compute_rsgm (:250-294).  The arithmetic
+// spec is DESIGN.md section 4 (= oracle/rsgm_oracle.c, the checker).
+//
+// Data layout in HBM (per frame, padded to Hp x Wp multiples of 16):
+//   gray    u8  [Hp][Wp]          census  u32 [Hp][Wp]  (24 bits used)
+//   path_k  u8|u16 [Hp][Wp][D]    one volume per path, D innermost ("xyd", rsgm.py:42)
+//   S       u16 [Hp][Wp][D]       disp    f32 [Hp][Wp]
+//
+// Wave64 mapping of the disparity axis: a 16-lane DPP row owns one pixel, lane l of the
+// row owns the DPL = D/16 consecutive disparities d = DPL*l .. DPL*l+DPL-1, packed two
+// per VGPR as u16 pairs (v_pk_add_u16 clamp / v_pk_min_u16 / v_pk_sub_u16).  The d+-1
+// exchange is one DPP row_shr/row_shl per pixel, min over d is an in-lane packed min tree
+// plus four DPP row_ror steps.  One wave therefore advances 4 scan lines at once.
+#include "vppx_internal.h"
+
+#define INVALID_DISP_COST 16u
+#define INVALID_DISP (-10.0f)
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u16 u16x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------
+// packed-u16 helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b)
+{
+    u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 pk_adds(u32 a, u32 b)
+{
+    u16x2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b)
+{
+    u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(u32, r);
+}
+__device__ __forceinline__ u32 pk_splat(u32 v) { return (v & 0xFFFFu) | (v << 16); }
+
+// DPP controls (gfx9): row_shl:n 0x100+n, row_shr:n 0x110+n, row_ror:n 0x120+n
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_keep(u32 old, u32 src)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ u32 row_min_u32(u32 v)
+{
+    v = min(v, dpp_keep<0x128>(v, v)); // row_ror:8
+    v = min(v, dpp_keep<0x124>(v, v)); // row_ror:4
+    v = min(v, dpp_keep<0x122>(v, v)); // row_ror:2
+    v = min(v, dpp_keep<0x121>(v, v)); // row_ror:1
+    return v;
+}
+__device__ __forceinline__ u32 row_or_u32(u32 v)
+{
+    v |= dpp_keep<0x128>(v, v);
+    v |= dpp_keep<0x124>(v, v);
+    v |= dpp_keep<0x122>(v, v);
+    v |= dpp_keep<0x121>(v, v);
+    return v;
+}
+
+// unaligned (4-byte aligned) vector loads/stores of NW dwords
+template <int NW>
+__device__ __forceinline__ void load_words(const u32 *p, u32 (&w)[NW])
+{
+    struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
+    struct __attribute__((packed, aligned(4))) V2 { u32x2 v; };
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= NW; i += 4) {
+        u32x4 t = ((const V4 *)(p + i))->v;
+        w[i] = t.x; w[i + 1] = t.y; w[i + 2] = t.z; w[i + 3] = t.w;
+    }
+#pragma unroll
+    for (; i + 2 <= NW; i += 2) {
+        u32x2 t = ((const V2 *)(p + i))->v;
+        w[i] = t.x; w[i + 1] = t.y;
+    }
+#pragma unroll
+    for (; i < NW; i++) w[i] = p[i];
+}
+template <int NW>
+__device__ __forceinline__ void store_words(u32 *p, const u32 (&w)[NW])
+{
+    struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
+    struct __attribute__((packed, aligned(4))) V2 { u32x2 v; };
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= NW; i += 4) {
+        u32x4 t = {w[i], w[i + 1], w[i + 2], w[i + 3]};
+        ((V4 *)(p + i))->v = t;
+    }
+#pragma unroll
+    for (; i + 2 <= NW; i += 2) {
+        u32x2 t = {w[i], w[i + 1]};
+        ((V2 *)(p + i))->v = t;
+    }
+#pragma unroll
+    for (; i < NW; i++) p[i] = w[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// pad (cv2.copyMakeBorder BORDER_REFLECT, rsgm.py:258-260) fused with RGB2GRAY
+// (rsgm.py:11-12): gray(pad(img)) == pad(gray(img)).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = (i < 0) ? (-i - 1) : (2 * n - i - 1);
+    return i;
+}
+
+__global__ void __launch_bounds__(256) pad_gray_kernel(const u8 *__restrict__ img, u8 *__restrict__ gray, int H, int W,
+                                                       int C, int Hp, int Wp, int pad_t, int pad_l)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= Wp) return;
+    const int sy = reflect_idx(y - pad_t, H), sx = reflect_idx(x - pad_l, W);
+    const u8 *s = img + (((size_t)f * H + sy) * W + sx) * C;
+    u32 v;
+    if (C == 3) {
+        v = (s[0] * 9798u + s[1] * 19235u + s[2] * 3735u + 16384u) >> 15;
+    } else {
+        v = s[0];
+    }
+    gray[((size_t)f * Hp + y) * Wp + x] = (u8)v;
+}
+
+int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gray)
+{
+    dim3 grid((g.Wp + 255) / 256, g.Hp, g.B);
+    pad_gray_kernel<<<grid, 256, 0, ctx->stream>>>(img, gray, g.H, g.W, g.C, g.Hp, g.Wp, g.pad_t, g.pad_l);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// census 5x5 (call site rsgm.py:25-26).  24 bits, row-major, first neighbour = bit 23,
+// bit = (neighbour < centre); 2-px border = 0.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) census5x5_kernel(const u8 *__restrict__ gray, u32 *__restrict__ out, int Hp, int Wp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= Wp) return;
+    const u8 *g = gray + (size_t)f * Hp * Wp;
+    u32 v = 0;
+    if (y >= 2 && y < Hp - 2 && x >= 2 && x < Wp - 2) {
+        const u32 c = g[(size_t)y * Wp + x];
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+            for (int dx = -2; dx <= 2; dx++) {
+                if (dy == 0 && dx == 0) continue;
+                v = (v << 1) | (u32)(g[(size_t)(y + dy) * Wp + (x + dx)] < c);
+            }
+    }
+    out[((size_t)f * Hp + y) * Wp + x] = v;
+}
+
+int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32 *census)
+{
+    dim3 grid((Wp + 255) / 256, Hp, B);
+    census5x5_kernel<<<grid, 256, 0, ctx->stream>>>(gray, census, Hp, Wp);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// materialised Hamming cost volume (call site rsgm.py:44) -- stage API only; the fused
+// path recomputes costs from the census pair inside the aggregation kernel.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cost_kernel(const u32 *__restrict__ cl, const u32 *__restrict__ cr,
+                                                   u16 *__restrict__ dsi, int Hp, int Wp, int D)
+{
+    // one thread per (pixel, d-pair)
+    const size_t npairs = (size_t)Hp * Wp * (D / 2);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.z;
+    if (i >= npairs) return;
+    const int dp = (int)(i % (D / 2));
+    const size_t pix = i / (D / 2);
+    const int x = (int)(pix % Wp);
+    const size_t base = (size_t)f * Hp * Wp;
+    const u32 a = cl[base + pix];
+    const int d0 = 2 * dp, d1 = d0 + 1;
+    u32 c0 = d0 <= x ? __popc(a ^ cr[base + pix - d0]) : INVALID_DISP_COST;
+    u32 c1 = d1 <= x ? __popc(a ^ cr[base + pix - d1]) : INVALID_DISP_COST;
+    ((u32 *)dsi)[base * (D / 2) + i] = c0 | (c1 << 16);
+}
+
+int rsgm_launch_cost(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u32 *cl, const u32 *cr, u16 *dsi)
+{
+    const size_t npairs = (size_t)Hp * Wp * (D / 2);
+    dim3 grid((unsigned)((npairs + 255) / 256), 1, B);
+    cost_kernel<<<grid, 256, 0, ctx->stream>>>(cl, cr, dsi, Hp, Wp, D);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// 8-path semi-global aggregation (call site rsgm.py:61, spec DESIGN 4.4).
+//   L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, min_k L_r(p-r,k)+P2)
+//              - min_k L_r(p-r,k)              (u16 saturating adds; missing predecessor: L=C)
+// Line-parallel: every scan line of every direction is an independent chain.  Vertical and
+// diagonal lines are "wrapped" (x = (s +- t) mod Wp, chain restarts at the image border) so
+// all of them have exactly Hp steps.  grid = (lines/16, 8 directions, B frames).
+// ---------------------------------------------------------------------------------------
+struct PathArgs {
+    const u8 *gray;
+    const u32 *cl;
+    const u32 *cr;
+    const u16 *dsi;
+    const u16 *p2lut;
+    void *out;
+    int Hp, Wp, D, p1;
+    size_t vol_elems; // elements per path volume (B*Hp*Wp*D)
+};
+
+template <int NP>
+__device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], u32 P1pk, u32 P2pk, u32 &minpk)
+{
+    const u32 left_in = dpp_keep<0x111>(0xFFFFFFFFu, L[NP - 1]); // row_shr:1 : lane-1's last pair
+    const u32 right_in = dpp_keep<0x101>(0xFFFFFFFFu, L[0]);     // row_shl:1 : lane+1's first pair
+    const u32 t2 = pk_adds(minpk, P2pk);
+    u32 Ln[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const u32 prevp = (i == 0) ? left_in : L[i - 1];
+        const u32 nextp = (i == NP - 1) ? right_in : L[i + 1];
+        const u32 dm1 = __builtin_amdgcn_alignbit(L[i], prevp, 16);  // {L[2i-1], L[2i]}
+        const u32 dp1 = __builtin_amdgcn_alignbit(nextp, L[i], 16);  // {L[2i+1], L[2i+2]}
+        u32 m = pk_adds(pk_min(dm1, dp1), P1pk);
+        m = pk_min(m, L[i]);
+        m = pk_min(m, t2);
+        m = pk_adds(m, C[i]);
+        Ln[i] = pk_sub(m, minpk);
+    }
+    u32 mm = Ln[0];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        L[i] = Ln[i];
+        mm = pk_min(mm, Ln[i]);
+    }
+    mm = min(mm & 0xFFFFu, mm >> 16);
+    mm = row_min_u32(mm);
+    minpk = pk_splat(mm);
+}
+
+template <int DPL, bool EXACT, bool FROM_DSI, typename OT>
+__global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
+{
+    constexpr int NP = DPL / 2;
+    __shared__ u16 s_lut[256];
+    s_lut[threadIdx.x] = a.p2lut[threadIdx.x];
+    __syncthreads();
+
+    const int dir = blockIdx.y;
+    const int f = blockIdx.z;
+    const bool horiz = (dir == 0 || dir == 4);
+    const int nlines = horiz ? a.Hp : a.Wp;
+    if ((int)blockIdx.x * 16 >= nlines) return;
+    int line = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool line_active = line < nlines; // partial last block: redo the last line, store nothing
+    line = line_active ? line : nlines - 1;
+    const int l16 = threadIdx.x & 15;
+    const int nsteps = horiz ? a.Wp : a.Hp;
+    const int Wp = a.Wp, Hp = a.Hp, D = a.D;
+
+    int x, y, dxs, dys;
+    if (horiz) {
+        y = line; dys = 0;
+        x = (dir == 0) ? 0 : Wp - 1;
+        dxs = (dir == 0) ? 1 : -1;
+    } else {
+        x = line;
+        const bool down = dir < 4; // 1,2,3 go down; 5,6,7 go up
+        y = down ? 0 : Hp - 1;
+        dys = down ? 1 : -1;
+        dxs = (dir == 2 || dir == 6) ? 0 : ((dir == 1 || dir == 7) ? 1 : -1);
+    }
+    const bool diag = (dxs != 0) && (dys != 0);
+    const int wrap_edge = dxs > 0 ? 0 : Wp - 1;
+
+    const int dbase = DPL * l16;
+    u32 inact[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) inact[i] = (!EXACT && (dbase + 2 * i >= D)) ? 0xFFFFFFFFu : 0u;
+
+    const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
+    OT *outv = (OT *)a.out + (size_t)dir * a.vol_elems;
+
+    u32 L[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) L[i] = 0;
+    u32 minpk = 0;
+    int prevI = 0;
+
+    for (int t = 0; t < nsteps; t++) {
+        const size_t pix = ((size_t)f * Hp + y) * Wp + x;
+        // ---- matching cost for this pixel ------------------------------------------------
+        u32 C[NP];
+        if (FROM_DSI) {
+            const u32 *cp = (const u32 *)(a.dsi + pix * D + dbase);
+            if (EXACT) {
+                load_words<NP>(cp, C);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NP; i++) C[i] = inact[i] ? 0u : cp[i];
+            }
+        } else {
+            u32 w[DPL];
+            load_words<DPL>(a.cr + pix - dbase - (DPL - 1), w); // w[j] = cr[x - (dbase + DPL-1-j)]
+            const u32 clv = a.cl[pix];
+            const int lim = x - dbase; // k valid iff k <= lim
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                u32 c0 = __popc(clv ^ w[DPL - 1 - 2 * i]);
+                u32 c1 = __popc(clv ^ w[DPL - 2 - 2 * i]);
+                C[i] = c0 | (c1 << 16);
+            }
+            // d > x has no right-image pixel: InvalidDispCost.  Wave-uniform branch: only the
+            // waves whose columns sit in the first D-1 pixels of a row pay for the selects.
+            if (__builtin_amdgcn_ballot_w64(lim < DPL - 1) != 0) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const u32 lo = (2 * i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
+                    const u32 hi = (2 * i + 1 <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
+                    C[i] = lo | (hi << 16);
+                }
+            }
+        }
+        const int I = a.gray[pix];
+        // ---- chain restart at the image border (missing predecessor => L = C) -------------
+        const bool reset = (t == 0) || (diag && x == wrap_edge);
+        u32 P2pk;
+        if (reset) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) L[i] = 0;
+            minpk = 0;
+            P2pk = 0;
+        } else {
+            int di = I - prevI;
+            di = di < 0 ? -di : di;
+            P2pk = pk_splat(s_lut[di]);
+        }
+        sgm_update<NP>(L, C, P1pk, P2pk, minpk);
+        if (!EXACT) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) L[i] |= inact[i];
+        }
+        // ---- store this path's L -----------------------------------------------------------
+        if (!line_active) {
+            // nothing to store
+        } else if (sizeof(OT) == 2) {
+            u32 *op = (u32 *)((u16 *)outv + pix * D + dbase);
+            if (EXACT) {
+                store_words<NP>(op, L);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NP; i++)
+                    if (!inact[i]) op[i] = L[i];
+            }
+        } else {
+            // u16 pairs -> bytes (values are < 256 by construction of the u8 variant)
+            u32 bw[(NP + 1) / 2];
+#pragma unroll
+            for (int i = 0; i + 1 < NP; i += 2) bw[i / 2] = __builtin_amdgcn_perm(L[i + 1], L[i], 0x06040200u);
+            u8 *ob = (u8 *)outv + pix * D + dbase;
+            if (EXACT) {
+                store_words<NP / 2>((u32 *)ob, (const u32(&)[NP / 2])bw);
+            } else {
+#pragma unroll
+                for (int i = 0; i + 1 < NP; i += 2)
+                    if (!inact[i]) *(u32 *)(ob + 2 * i) = bw[i / 2]; // D % 4 == 0 keeps pairs of pairs together
+            }
+        }
+        prevI = I;
+        x += dxs;
+        x = x >= Wp ? x - Wp : (x < 0 ? x + Wp : x);
+        y += dys;
+    }
+}
+
+template <int DPL, bool EXACT>
+static int launch_paths_t(vppx_ctx *ctx, const PathArgs &a, int B, bool from_dsi, int elem_bytes)
+{
+    const int nl = a.Hp > a.Wp ? a.Hp : a.Wp;
+    dim3 grid((nl + 15) / 16, 8, B);
+    if (from_dsi) {
+        sgm_paths_kernel<DPL, EXACT, true, u16><<<grid, 256, 0, ctx->stream>>>(a);
+    } else if (elem_bytes == 2) {
+        sgm_paths_kernel<DPL, EXACT, false, u16><<<grid, 256, 0, ctx->stream>>>(a);
+    } else {
+        sgm_paths_kernel<DPL, EXACT, false, u8><<<grid, 256, 0, ctx->stream>>>(a);
+    }
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline int dpl_for(int D) { return D <= 64 ? 4 : (D <= 128 ? 8 : (D <= 192 ? 12 : 16)); }
+
+int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
+                      const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes)
+{
+    PathArgs a;
+    a.gray = gray; a.cl = cl; a.cr = cr; a.dsi = dsi; a.p2lut = p2lut; a.out = paths;
+    a.Hp = Hp; a.Wp = Wp; a.D = D; a.p1 = p1;
+    a.vol_elems = (size_t)B * Hp * Wp * D;
+    const int dpl = dpl_for(D);
+    const bool exact = (D == 16 * dpl);
+    const bool from_dsi = dsi != nullptr;
+    if (from_dsi || !exact) elem_bytes = 2; // those variants always write u16 volumes
+    switch (dpl) {
+    case 4: return exact ? launch_paths_t<4, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<4, false>(ctx, a, B, from_dsi, elem_bytes);
+    case 8: return exact ? launch_paths_t<8, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<8, false>(ctx, a, B, from_dsi, elem_bytes);
+    case 12: return exact ? launch_paths_t<12, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<12, false>(ctx, a, B, from_dsi, elem_bytes);
+    default: return exact ? launch_paths_t<16, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<16, false>(ctx, a, B, from_dsi, elem_bytes);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// S = sum of the 8 path volumes, fused with the left WTA + uniqueness (rsgm.py:141) and the
+// equiangular sub-pixel refinement (rsgm.py:142).  One 16-lane row per pixel.
+// ---------------------------------------------------------------------------------------
+template <int DPL>
+__device__ __forceinline__ float wta_rows(const u32 (&S)[DPL / 2], int dbase, int n /*valid d: d < n*/, int D,
+                                          u32 factor_uniq, bool do_subpixel, bool x_interior)
+{
+    constexpr int NP = DPL / 2;
+    // key = cost*256 + d : first minimum wins on ties
+    u32 key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int d0 = dbase + 2 * i, d1 = d0 + 1;
+        const u32 k0 = d0 < n ? (((S[i] & 0xFFFFu) << 8) | (u32)d0) : 0xFFFFFFFFu;
+        const u32 k1 = d1 < n ? (((S[i] >> 16) << 8) | (u32)d1) : 0xFFFFFFFFu;
+        key = min(key, min(k0, k1));
+    }
+    key = row_min_u32(key);
+    const int best = (int)(key & 0xFFu);
+    const u32 minc = key >> 8;
+    u32 sec = 65535u, cm1 = 0, cp1 = 0, nbhit = 0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int d0 = dbase + 2 * i, d1 = d0 + 1;
+        const u32 s0 = S[i] & 0xFFFFu, s1 = S[i] >> 16;
+        if (d0 < n && d0 != best) sec = min(sec, s0);
+        if (d1 < n && d1 != best) sec = min(sec, s1);
+        if (d0 == best - 1) cm1 = s0;
+        if (d1 == best - 1) cm1 = s1;
+        if (d0 == best + 1) cp1 = s0;
+        if (d1 == best + 1) cp1 = s1;
+    }
+    sec = row_min_u32(sec);
+    cm1 = row_or_u32(cm1);
+    cp1 = row_or_u32(cp1);
+    (void)nbhit;
+    bool ok = (1024u * minc <= sec * factor_uniq);
+    if (!ok) {
+        if (best > 0 && cm1 == sec) ok = true;
+        if (best + 1 < n && cp1 == sec) ok = true;
+    }
+    float disp = ok ? (float)best : INVALID_DISP;
+    if (do_subpixel && x_interior && disp > 0.0f && best >= 1 && best <= D - 2) {
+        const int c0 = (int)cm1, c1 = (int)minc, c2 = (int)cp1;
+        const int den = (c2 < c0) ? c0 - c1 : c2 - c1;
+        if (den != 0) disp = (float)best + __fdiv_rn((float)(c0 - c2), __fmul_rn(2.0f, (float)den));
+    }
+    return disp;
+}
+
+template <int DPL, bool EXACT, typename IT>
+__global__ void __launch_bounds__(256) sum_wta_kernel(const IT *__restrict__ paths, size_t vol_elems, u16 *__restrict__ S,
+                                                      float *__restrict__ disp, int Hp, int Wp, int D, u32 factor_uniq,
+                                                      int do_subpixel)
+{
+    constexpr int NP = DPL / 2;
+    const size_t npix = (size_t)gridDim.z * 0 + (size_t)Hp * Wp; // per frame
+    const size_t pl = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int f = blockIdx.z;
+    if (pl >= npix) return;
+    const size_t pix = (size_t)f * npix + pl;
+    const int x = (int)(pl % Wp);
+    const int l16 = threadIdx.x & 15;
+    const int dbase = DPL * l16;
+    u32 acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) acc[i] = 0;
+    const bool lane_active = EXACT || (dbase < D);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const IT *vp = paths + (size_t)k * vol_elems + pix * D + dbase;
+        if (sizeof(IT) == 2) {
+            u32 w[NP];
+            if (EXACT) {
+                load_words<NP>((const u32 *)vp, w);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NP; i++) w[i] = (dbase + 2 * i < D) ? ((const u32 *)vp)[i] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], w[i]);
+        } else {
+            u32 w[NP / 2];
+            load_words<NP / 2>((const u32 *)vp, w);
+#pragma unroll
+            for (int i = 0; i < NP / 2; i++) {
+                acc[2 * i] = pk_adds(acc[2 * i], __builtin_amdgcn_perm(w[i], w[i], 0x0c010c00u));
+                acc[2 * i + 1] = pk_adds(acc[2 * i + 1], __builtin_amdgcn_perm(w[i], w[i], 0x0c030c02u));
+            }
+        }
+    }
+    if (S) {
+        u32 *sp = (u32 *)(S + pix * D + dbase);
+        if (EXACT) {
+            store_words<NP>(sp, acc);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                if (dbase + 2 * i < D) sp[i] = acc[i];
+        }
+    }
+    (void)lane_active;
+    if (disp) {
+        const int n = (x < D - 1 ? x : D - 1) + 1;
+        const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
+        if (l16 == 0) disp[pix] = dv;
+    }
+}
+
+template <int DPL>
+static int launch_sum_wta_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
+                            float *disp, u32 fu, int sub)
+{
+    const size_t npix = (size_t)Hp * Wp;
+    dim3 grid((unsigned)((npix + 15) / 16), 1, B);
+    const size_t vol = (size_t)B * npix * D;
+    const bool exact = (D == 16 * DPL);
+    if (elem_bytes == 1) {
+        sum_wta_kernel<DPL, true, u8><<<grid, 256, 0, ctx->stream>>>((const u8 *)paths, vol, S, disp, Hp, Wp, D, fu, sub);
+    } else if (exact) {
+        sum_wta_kernel<DPL, true, u16><<<grid, 256, 0, ctx->stream>>>((const u16 *)paths, vol, S, disp, Hp, Wp, D, fu, sub);
+    } else {
+        sum_wta_kernel<DPL, false, u16><<<grid, 256, 0, ctx->stream>>>((const u16 *)paths, vol, S, disp, Hp, Wp, D, fu, sub);
+    }
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
+                        float *disp_l, u32 factor_uniq, int do_subpixel)
+{
+    const int dpl = dpl_for(D);
+    if (D != 16 * dpl) elem_bytes = 2;
+    switch (dpl) {
+    case 4: return launch_sum_wta_t<4>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
+    case 8: return launch_sum_wta_t<8>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
+    case 12: return launch_sum_wta_t<12>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
+    default: return launch_sum_wta_t<16>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stand-alone left WTA / sub-pixel on a materialised S (stage API: rsgm.py:141-142)
+// ---------------------------------------------------------------------------------------
+template <int DPL, bool SUBPIX_ONLY>
+__global__ void __launch_bounds__(256) wta_left_kernel(const u16 *__restrict__ S, float *__restrict__ disp, int Hp, int Wp,
+                                                       int D, u32 factor_uniq)
+{
+    constexpr int NP = DPL / 2;
+    const size_t npix = (size_t)Hp * Wp;
+    const size_t pl = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int f = blockIdx.z;
+    if (pl >= npix) return;
+    const size_t pix = (size_t)f * npix + pl;
+    const int x = (int)(pl % Wp);
+    const int l16 = threadIdx.x & 15;
+    const int dbase = DPL * l16;
+    u32 acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) acc[i] = (dbase + 2 * i < D) ? ((const u32 *)(S + pix * D + dbase))[i] : 0xFFFFFFFFu;
+    if (!SUBPIX_ONLY) {
+        const int n = (x < D - 1 ? x : D - 1) + 1;
+        const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, false, false);
+        if (l16 == 0) disp[pix] = dv;
+    } else {
+        // subPixelRefine(dsi, disp, ..., method 0): refine an existing integer disparity
+        const float dv = disp[pix];
+        if (x >= 1 && x <= Wp - 2 && dv > 0.0f) {
+            const int best = (int)dv;
+            u32 cm1 = 0, c1 = 0, cp1 = 0;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int d0 = dbase + 2 * i, d1 = d0 + 1;
+                const u32 s0 = acc[i] & 0xFFFFu, s1 = acc[i] >> 16;
+                if (d0 == best - 1) cm1 = s0;
+                if (d1 == best - 1) cm1 = s1;
+                if (d0 == best) c1 = s0;
+                if (d1 == best) c1 = s1;
+                if (d0 == best + 1) cp1 = s0;
+                if (d1 == best + 1) cp1 = s1;
+            }
+            cm1 = row_or_u32(cm1); c1 = row_or_u32(c1); cp1 = row_or_u32(cp1);
+            if (best >= 1 && best <= D - 2) {
+                const int c0 = (int)cm1, cc = (int)c1, c2 = (int)cp1;
+                const int den = (c2 < c0) ? c0 - cc : c2 - cc;
+                if (den != 0 && l16 == 0)
+                    disp[pix] = (float)best + __fdiv_rn((float)(c0 - c2), __fmul_rn(2.0f, (float)den));
+            }
+        }
+    }
+}
+
+int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 fu)
+{
+    const size_t npix = (size_t)Hp * Wp;
+    dim3 grid((unsigned)((npix + 15) / 16), 1, B);
+    switch (dpl_for(D)) {
+    case 4: wta_left_kernel<4, false><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, fu); break;
+    case 8: wta_left_kernel<8, false><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, fu); break;
+    case 12: wta_left_kernel<12, false><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, fu); break;
+    default: wta_left_kernel<16, false><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, fu); break;
+    }
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp)
+{
+    const size_t npix = (size_t)Hp * Wp;
+    dim3 grid((unsigned)((npix + 15) / 16), 1, B);
+    switch (dpl_for(D)) {
+    case 4: wta_left_kernel<4, true><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, 0); break;
+    case 8: wta_left_kernel<8, true><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, 0); break;
+    case 12: wta_left_kernel<12, true><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, 0); break;
+    default: wta_left_kernel<16, true><<<grid, 256, 0, ctx->stream>>>(S, disp, Hp, Wp, D, 0); break;
+    }
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// right-view WTA (call site rsgm.py:170): d_R(y,x) = argmin_d S[y, x+d, d].
+// A block owns XR consecutive right pixels of one row.  The diagonal band of S it needs is
+// staged through LDS with coalesced reads: for source pixel xs the needed disparities are
+// d in [xs-x0-XR+1, xs-x0] (contiguous), so every S element is read exactly once overall.
+// LDS image: band[xs_local][j], j = d - (xs_local - XR + 1), i.e. band[xs_local][j] belongs
+// to right pixel xr_local = XR-1-j.
+// ---------------------------------------------------------------------------------------
+#define XR 64
+__global__ void __launch_bounds__(256) wta_right_kernel(const u16 *__restrict__ S, float *__restrict__ disp, int Hp, int Wp,
+                                                        int D, u32 factor_uniq)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 band[]; // [(XR + D - 1)][XR]
+    const int x0 = blockIdx.x * XR;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    const size_t rowbase = ((size_t)f * Hp + y) * Wp;
+    const int nsrc = XR + D - 1;
+    // stage: XR entries per source pixel
+    for (int e = threadIdx.x; e < nsrc * XR; e += blockDim.x) {
+        const int xsl = e / XR, j = e % XR;
+        const int xs = x0 + xsl;
+        const int d = xsl - XR + 1 + j;
+        u16 v = 0xFFFF;
+        if (xs < Wp && d >= 0 && d < D) v = S[(rowbase + xs) * D + d];
+        band[e] = v;
+    }
+    __syncthreads();
+    // 4 threads per right pixel: thread q handles d = q, q+4, ...
+    const int xrl = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int xr = x0 + xrl;
+    const int n = xr < Wp ? ((Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1) : 0;
+    // cost of (xr, d) = band[xrl + d][XR-1-xrl]
+    const int j = XR - 1 - xrl;
+    u32 key = 0xFFFFFFFFu;
+    for (int d = q; d < n; d += 4) {
+        const u32 c = band[(xrl + d) * XR + j];
+        key = min(key, (c << 8) | (u32)d);
+    }
+    // reduce over the 4 threads (quad_perm DPP)
+    key = min(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, false)); // quad_perm [1,0,3,2]
+    key = min(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, false)); // quad_perm [2,3,0,1]
+    const int best = (int)(key & 0xFFu);
+    const u32 minc = key >> 8;
+    u32 sec = 65535u;
+    for (int d = q; d < n; d += 4) {
+        if (d != best) sec = min(sec, (u32)band[(xrl + d) * XR + j]);
+    }
+    sec = min(sec, (u32)__builtin_amdgcn_update_dpp(0, (int)sec, 0xB1, 0xF, 0xF, false));
+    sec = min(sec, (u32)__builtin_amdgcn_update_dpp(0, (int)sec, 0x4E, 0xF, 0xF, false));
+    if (q == 0 && xr < Wp) {
+        bool ok = (1024u * minc <= sec * factor_uniq);
+        if (!ok) {
+            if (best > 0 && (u32)band[(xrl + best - 1) * XR + j] == sec) ok = true;
+            if (best + 1 < n && (u32)band[(xrl + best + 1) * XR + j] == sec) ok = true;
+        }
+        disp[rowbase + xr] = ok ? (float)best : INVALID_DISP;
+    }
+}
+
+int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 fu)
+{
+    dim3 grid((Wp + XR - 1) / XR, Hp, B);
+    const size_t lds = (size_t)(XR + D - 1) * XR * sizeof(u16);
+    wta_right_kernel<<<grid, 256, lds, ctx->stream>>>(S, disp, Hp, Wp, D, fu);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// median3x3 on float32 (call sites rsgm.py:145,173): exact median inside, border copied.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(float &a, float &b)
+{
+    const float lo = fminf(a, b), hi = fmaxf(a, b);
+    a = lo; b = hi;
+}
+__global__ void __launch_bounds__(256) median3x3_kernel(const float *__restrict__ src, float *__restrict__ dst, int Hp, int Wp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= Wp) return;
+    const float *s = src + (size_t)f * Hp * Wp;
+    float out;
+    if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
+        out = s[(size_t)y * Wp + x];
+    } else {
+        float v[9];
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) v[(dy + 1) * 3 + dx + 1] = s[(size_t)(y + dy) * Wp + x + dx];
+        // 19-comparator median-of-9 network
+        cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+        cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+        cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+        cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+        cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+        cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+        cswap(v[4], v[2]);
+        out = v[4];
+    }
+    dst[((size_t)f * Hp + y) * Wp + x] = out;
+}
+
+int rsgm_launch_median(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, float *dst)
+{
+    dim3 grid((Wp + 255) / 256, Hp, B);
+    median3x3_kernel<<<grid, 256, 0, ctx->stream>>>(src, dst, Hp, Wp);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// _linear_interpolate(dmap, 15, 3) (rsgm.py:67-113) + np.clip(.,0,None) (:151,179).
+// In place and raster-sequential in the reference (a fill rewrites the two end points that
+// the next gap reads), so each row is one sequential chain: one wave per row, the row lives
+// in LDS, lane 0 walks it.  O(Hp) parallel chains per frame; cost is a few microseconds.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) linear_interp_clip_kernel(float *__restrict__ disp, int Hp, int Wp)
+{
+    extern __shared__ __attribute__((aligned(16))) float row[];
+    const int y = blockIdx.x, f = blockIdx.y;
+    float *g = disp + ((size_t)f * Hp + y) * Wp;
+    for (int x = threadIdx.x; x < Wp; x += 64) row[x] = g[x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = 15 / 2;
+        for (int x = 0; x < Wp; x++) {
+            if (row[x] <= 0) {
+                double n_left = 0, n_right = 0;
+                int n_leftx = 0, n_rightx = 0;
+                for (int xw = -1; xw > -n - 1; xw--)
+                    if (0 <= x + xw && x + xw < Wp && row[x + xw] > 0) {
+                        n_left = (double)row[x + xw]; n_leftx = xw; break;
+                    }
+                for (int xw = 1; xw < n + 1; xw++)
+                    if (0 <= x + xw && x + xw < Wp && row[x + xw] > 0) {
+                        n_right = (double)row[x + xw]; n_rightx = xw; break;
+                    }
+                if (n_left > 0 && n_right > 0 && fabs(n_left - n_right) < 3.0) {
+                    const double m = __ddiv_rn(n_right - n_left, (double)(n_rightx - n_leftx));
+                    const double q = __dsub_rn(n_left, __dmul_rn(m, (double)n_leftx));
+                    for (int xw = n_leftx; xw < n_rightx + 1; xw++)
+                        row[x + xw] = (float)__dadd_rn(__dmul_rn(m, (double)xw), q);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < Wp; x += 64) {
+        const float v = row[x];
+        g[x] = (v >= 0) ? v : 0.0f; // np.clip(., 0, None); NaN cannot occur
+    }
+}
+
+int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, float *disp)
+{
+    dim3 grid(Hp, B);
+    linear_interp_clip_kernel<<<grid, 64, (size_t)Wp * sizeof(float), ctx->stream>>>(disp, Hp, Wp);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// post-processing of compute_rsgm (rsgm.py:275-292) on the cropped frame:
+//   crop -> left/right check (:230-248) -> zero mask==128 -> astype(uint8) -> filterSpeckles
+//   (0,200,10) -> astype(float32) -> restore sub-pixel -> _interpolate_background (:185-227)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) crop_lrc_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
+                                                       float *__restrict__ fdc, u8 *__restrict__ fd8, int *__restrict__ label,
+                                                       int H, int W, int Hp, int Wp, int pad_t, int pad_l)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const float *rl = dl + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
+    const float *rr = dr + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
+    const float v = rl[x];
+    float keep = v;
+    if (v > 0) {
+        const int d = (int)rintf(v); // round half to even (numba round)
+        const int xd = x - d;
+        if (0 <= xd && xd <= W - 1) {
+            const float rv = rr[xd];
+            if (rv > 0 && fabsf(__fsub_rn(v, rv)) > 1.0f) keep = 0; // mask 128
+        } else {
+            keep = 0; // mask 128
+        }
+    }
+    const size_t o = ((size_t)f * H + y) * W + x;
+    fdc[o] = v;
+    fd8[o] = (u8)keep; // astype(np.uint8): truncation, values in [0,256)
+    label[o] = (int)((size_t)y * W + x);
+}
+
+// union-find connected components (4-connectivity, |a-b| <= maxDiff, pixels == newVal excluded)
+__device__ __forceinline__ int uf_find(int *label, int i)
+{
+    int p = label[i];
+    while (p != i) {
+        i = p;
+        p = label[i];
+    }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int *label, int a, int b)
+{
+    while (true) {
+        a = uf_find(label, a);
+        b = uf_find(label, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; } // a > b : hang a under b
+        const int old = atomicMin(&label[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+__global__ void __launch_bounds__(256) speckle_union_kernel(const u8 *__restrict__ img, int *__restrict__ label, int H, int W,
+                                                            int new_val, int max_diff)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const u8 *im = img + (size_t)f * H * W;
+    int *lb = label + (size_t)f * H * W;
+    const int i = y * W + x;
+    const int v = im[i];
+    if (v == new_val) return;
+    if (x + 1 < W) {
+        const int u = im[i + 1];
+        if (u != new_val && abs(v - u) <= max_diff) uf_union(lb, i, i + 1);
+    }
+    if (y + 1 < H) {
+        const int u = im[i + W];
+        if (u != new_val && abs(v - u) <= max_diff) uf_union(lb, i, i + W);
+    }
+}
+__global__ void __launch_bounds__(256) speckle_count_kernel(const u8 *__restrict__ img, int *__restrict__ label,
+                                                            int *__restrict__ count, int H, int W, int new_val)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t base = (size_t)f * H * W;
+    const int i = y * W + x;
+    if (img[base + i] == new_val) return;
+    const int r = uf_find(label + base, i);
+    label[base + i] = r; // flatten (roots are fixed points, so concurrent flattening is benign)
+    atomicAdd(&count[base + r], 1);
+}
+__global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict__ fd8, const int *__restrict__ label,
+                                                            const int *__restrict__ count, const float *__restrict__ fdc,
+                                                            float *__restrict__ out, int H, int W, int new_val, int max_size,
+                                                            int subpixel)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t o = ((size_t)f * H + y) * W + x;
+    int v = fd8[o];
+    if (v != new_val) {
+        const int r = uf_find((int *)label + (size_t)f * H * W, y * W + x);
+        if (count[(size_t)f * H * W + r] <= max_size) v = new_val;
+    }
+    float fv = (float)v;                       // rsgm.py:286
+    if (subpixel && fv != 0.0f) fv = fdc[o];   // rsgm.py:289-290
+    out[o] = fv;
+}
+
+// _interpolate_background rows (rsgm.py:189-214): one thread per row, row staged in LDS by the wave
+__global__ void __launch_bounds__(64) interp_bg_rows_kernel(float *__restrict__ dm, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) float row[];
+    const int y = blockIdx.x, f = blockIdx.y;
+    float *g = dm + ((size_t)f * H + y) * W;
+    for (int x = threadIdx.x; x < W; x += 64) row[x] = g[x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int count = 0;
+        for (int u = 0; u < W; u++) {
+            if (row[u] > 0) {
+                if (count >= 1) {
+                    const int u1 = u - count, u2 = u - 1;
+                    if (u1 > 0 && u2 < W - 1) {
+                        const float a = row[u1 - 1], b = row[u2 + 1];
+                        const float d_ipol = b < a ? b : a;
+                        for (int uc = u1; uc <= u2; uc++) row[uc] = d_ipol;
+                    }
+                }
+                count = 0;
+            } else {
+                count++;
+            }
+        }
+        for (int u = 0; u < W; u++)
+            if (row[u] > 0) {
+                for (int u2 = 0; u2 < u; u2++) row[u2] = row[u];
+                break;
+            }
+        for (int u = W - 1; u >= 0; u--)
+            if (row[u] > 0) {
+                for (int u2 = u + 1; u2 < W; u2++) row[u2] = row[u];
+                break;
+            }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 64) g[x] = row[x];
+}
+// columns (rsgm.py:216-227): one thread per column (coalesced across threads)
+__global__ void __launch_bounds__(256) interp_bg_cols_kernel(float *__restrict__ dm, int H, int W)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (u >= W) return;
+    float *g = dm + (size_t)f * H * W;
+    int first = -1, last = -1;
+    for (int v = 0; v < H; v++)
+        if (g[(size_t)v * W + u] > 0) { first = v; break; }
+    if (first < 0) return;
+    {
+        const float fv = g[(size_t)first * W + u];
+        for (int v2 = 0; v2 < first; v2++) g[(size_t)v2 * W + u] = fv;
+    }
+    for (int v = H - 1; v >= 0; v--)
+        if (g[(size_t)v * W + u] > 0) { last = v; break; }
+    {
+        const float lv = g[(size_t)last * W + u];
+        for (int v2 = last + 1; v2 < H; v2++) g[(size_t)v2 * W + u] = lv;
+    }
+}
+
+int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
+                     float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out)
+{
+    (void)fd;
+    dim3 grid((g.W + 255) / 256, g.H, g.B);
+    const size_t n = (size_t)g.B * g.H * g.W;
+    crop_lrc_kernel<<<grid, 256, 0, ctx->stream>>>(dl_pad, dr_pad, fdc, fd8, label, g.H, g.W, g.Hp, g.Wp, g.pad_t, g.pad_l);
+    VPPX_CHECK_LAUNCH();
+    VPPX_HIP(hipMemsetAsync(lcount, 0, n * sizeof(int), ctx->stream));
+    speckle_union_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, g.H, g.W, 0, 10);
+    VPPX_CHECK_LAUNCH();
+    speckle_count_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, lcount, g.H, g.W, 0);
+    VPPX_CHECK_LAUNCH();
+    speckle_apply_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, lcount, fdc, out, g.H, g.W, 0, 200, subpixel);
+    VPPX_CHECK_LAUNCH();
+    interp_bg_rows_kernel<<<dim3(g.H, g.B), 64, (size_t)g.W * sizeof(float), ctx->stream>>>(out, g.H, g.W);
+    VPPX_CHECK_LAUNCH();
+    interp_bg_cols_kernel<<<dim3((g.W + 255) / 256, g.B), 256, 0, ctx->stream>>>(out, g.H, g.W);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}

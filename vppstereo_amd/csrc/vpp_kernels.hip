@@ -1,0 +1,800 @@
+// vpp_kernels.hip -- virtual pattern projection on gfx950, hand-written HIP.
+//
+// Replaces the reference's sequential scan kernels for the hot path:
+//   vpp_core/vpp_core_opt.pyx:53-131  virtual_projection_scan_rnd      (bit-exact target)
+//   vpp_core/vpp_core_opt.pyx:133-341 virtual_projection_scan_max_dist (bit-exact target)
+//   vpp_standalone.py:243-369 / :14-232 numba twins (extra gates only)
+//   filter.py:246-292 occlusion_heuristic (producer of g_occ)
+//
+// The reference scan is strictly sequential (every hint blends a patch into BOTH images in
+// place and later hints read what earlier ones wrote).  The parallel formulation used here
+// (verified against the oracle): the total order of side effects is
+// (hint rank in scan order, channel, yw, xw, slot); channels are independent; a write to an
+// R pixel reads only that R pixel; a write to an L pixel reads only that L pixel plus, for
+// occluded hints, R "as of that instant".  So every output pixel replays, in key order,
+// exactly the ops that touch it:
+//   1. compact_kernel : per row, hints in scan order + prefix sums of their rand() draws
+//   2. rowscan_kernel : prefix over rows -> absolute position of every draw in the stream
+//   3. rand_kernel    : glibc TYPE_3 rand() stream generated in parallel by polynomial
+//                       jump-ahead (x_n = x_{n-3} + x_{n-31} mod 2^32 is linear)
+//   4. apply_l_kernel : one thread per L pixel (replays the R sub-chain for occluded hints)
+//   5. apply_r_kernel : one thread per R pixel
+// Mixed float32/float64 blend arithmetic follows the C that Cython generates;
+// the library is compiled with -ffp-contract=off and uses explicit _rn intrinsics.
+#include "vppx_internal.h"
+
+#include <math.h>
+#include <string.h>
+#include <mutex>
+
+#define LG 992 // draws per generator thread (32 passes over the 31-word ring)
+
+struct HintRec { // 16 bytes, one per hint, row-compacted in scan order
+    int x;
+    float g;
+    u32 base;  // first draw of this hint relative to the row's first draw
+    u32 flags; // bit0 occluded, bits 8..15 patch radius n_k, bits 16..31 cnt (draws per channel, non-uniform)
+};
+
+struct VppK {
+    int B, H, W, C;
+    int n, direction, uniform, discard, interp, use_dist, use_bil;
+    float c, c_occ, dmin, dmax;
+    double inv_gamma;
+    u8 *l;
+    u8 *r;
+    const float *g;
+    const u8 *occ;       // may be null
+    const float *filled; // may be null
+    HintRec *rec;        // [B][H][W]
+    uint2 *dense;        // [B][H][W] {idx in row, base in row}
+    int *row_count;      // [B][H]
+    u32 *row_draws;      // [B][H]
+    u32 *row_base;       // [B][H]
+    unsigned long long *frame_tot; // [B][2] {draws, hints}
+    const u8 *rnd;       // [B][rnd_cap]
+    size_t rnd_cap;
+};
+
+// ---------------------------------------------------------------------------------------
+// per-hint helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int patch_radius(const VppK &k, float gv)
+{
+    if (!k.use_dist) return k.n;
+    // vpp_standalone.py:7-11 with numba typing: float32 ratio, float64 pow, round half-to-even
+    const float num = __fsub_rn(gv, k.dmin);
+    const float den = __fsub_rn(k.dmax, k.dmin);
+    const float ratio = __fdiv_rn(num, den);
+    const double gw = pow((double)ratio, k.inv_gamma);
+    const double ws = rint(__dadd_rn(__dmul_rn(gw, (double)(2 * k.n)), 1.0)); // patch_size-1 == 2n for odd wsize
+    long long wsize = (long long)ws;
+    long long a = wsize - 1;
+    long long nn = a >= 0 ? a / 2 : -((-a + 1) / 2);
+    if (nn < 0) nn = -1; // empty patch
+    if (nn > k.n) nn = k.n;
+    return (int)nn;
+}
+
+__device__ __forceinline__ bool gate_pass(const VppK &k, int f, float gv, int yy, int xx)
+{
+    // vpp_standalone.py:154,335: abs(g[y,x] - filled_g[y+yw,x+xw]) < 0.1 in float64
+    const float fg = k.filled[((size_t)f * k.H + yy) * k.W + xx];
+    return fabs((double)gv - (double)fg) < 0.1;
+}
+
+// number of rand() draws one channel of this hint consumes (non-uniform colour) and, for a
+// patch pixel, its rank among the drawing pixels
+__device__ __forceinline__ int hint_cnt(const VppK &k, int f, int y, int x, float gv, int nk)
+{
+    if (nk < 0) return 0;
+    const int ywmin = max(-nk, -y), ywmax = min(nk, k.H - 1 - y);
+    const int xwmin = max(-nk, -x), xwmax = min(nk, k.W - 1 - x);
+    if (!k.use_bil) return (ywmax - ywmin + 1) * (xwmax - xwmin + 1);
+    int c = 0;
+    for (int yw = ywmin; yw <= ywmax; yw++)
+        for (int xw = xwmin; xw <= xwmax; xw++) c += gate_pass(k, f, gv, y + yw, x + xw) ? 1 : 0;
+    return c;
+}
+__device__ __forceinline__ int hint_idx(const VppK &k, int f, int y, int x, float gv, int nk, int yw0, int xw0)
+{
+    const int ywmin = max(-nk, -y);
+    const int xwmin = max(-nk, -x), xwmax = min(nk, k.W - 1 - x);
+    if (!k.use_bil) return (yw0 - ywmin) * (xwmax - xwmin + 1) + (xw0 - xwmin);
+    int c = 0;
+    for (int yw = ywmin; yw <= yw0; yw++)
+        for (int xw = xwmin; xw <= xwmax; xw++) {
+            if (yw == yw0 && xw >= xw0) break;
+            c += gate_pass(k, f, gv, y + yw, x + xw) ? 1 : 0;
+        }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1. row compaction in scan order (vpp_core_opt.pyx:77-81,129; gt_reshape :352-371)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) compact_kernel(VppK k)
+{
+    __shared__ u32 s_cnt[4], s_drw[4];
+    __shared__ u32 s_run_cnt, s_run_drw;
+    const int y = blockIdx.x, f = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_run_cnt = 0; s_run_drw = 0; }
+    __syncthreads();
+    const size_t rowoff = ((size_t)f * k.H + y) * k.W;
+    for (int p0 = 0; p0 < k.W; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        const int x = k.direction ? p : k.W - 1 - p;
+        float gv = 0.f;
+        bool is = false;
+        if (p < k.W) {
+            gv = k.g[rowoff + x];
+            is = gv > 0; // NaN and <= 0 are skipped (vpp_core_opt.pyx:81)
+        }
+        int nk = 0;
+        u32 cnt = 0, drw = 0;
+        if (is) {
+            nk = patch_radius(k, gv);
+            cnt = (u32)hint_cnt(k, f, y, x, gv, nk);
+            drw = k.uniform ? (u32)k.C : (u32)k.C * cnt;
+        }
+        // block exclusive scan of (is, drw)
+        u32 vc = is ? 1u : 0u, vd = drw;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 tc = __shfl_up(vc, off), td = __shfl_up(vd, off);
+            if (lane >= off) { vc += tc; vd += td; }
+        }
+        if (lane == 63) { s_cnt[wv] = vc; s_drw[wv] = vd; }
+        __syncthreads();
+        u32 pc = s_run_cnt, pd = s_run_drw;
+        for (int w = 0; w < wv; w++) { pc += s_cnt[w]; pd += s_drw[w]; }
+        const u32 my_idx = pc + vc - (is ? 1u : 0u);
+        const u32 my_base = pd + vd - drw;
+        if (is) {
+            HintRec r;
+            r.x = x;
+            r.g = gv;
+            r.base = my_base;
+            const u32 occ = (k.occ && k.occ[rowoff + x] != 0) ? 1u : 0u;
+            r.flags = occ | ((u32)(nk & 0xFF) << 8) | ((cnt & 0xFFFFu) << 16);
+            k.rec[rowoff + my_idx] = r;
+            k.dense[rowoff + x] = make_uint2(my_idx, my_base);
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) {
+            s_run_cnt = pc + vc;
+            s_run_drw = pd + vd;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        k.row_count[(size_t)f * k.H + y] = (int)s_run_cnt;
+        k.row_draws[(size_t)f * k.H + y] = s_run_drw;
+    }
+}
+
+// 2. exclusive scan of the per-row draw counts (one block per frame)
+__global__ void __launch_bounds__(256) rowscan_kernel(VppK k, long long *n_hints_out)
+{
+    __shared__ unsigned long long s_d[4], s_c[4];
+    __shared__ unsigned long long s_run_d, s_run_c;
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_run_d = 0; s_run_c = 0; }
+    __syncthreads();
+    for (int y0 = 0; y0 < k.H; y0 += 256) {
+        const int y = y0 + threadIdx.x;
+        unsigned long long d = 0, c = 0;
+        if (y < k.H) {
+            d = k.row_draws[(size_t)f * k.H + y];
+            c = (unsigned long long)k.row_count[(size_t)f * k.H + y];
+        }
+        unsigned long long vd = d, vc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long td = __shfl_up(vd, off), tc = __shfl_up(vc, off);
+            if (lane >= off) { vd += td; vc += tc; }
+        }
+        if (lane == 63) { s_d[wv] = vd; s_c[wv] = vc; }
+        __syncthreads();
+        unsigned long long pd = s_run_d, pc = s_run_c;
+        for (int w = 0; w < wv; w++) { pd += s_d[w]; pc += s_c[w]; }
+        if (y < k.H) k.row_base[(size_t)f * k.H + y] = (u32)(pd + vd - d);
+        __syncthreads();
+        if (threadIdx.x == 255) { s_run_d = pd + vd; s_run_c = pc + vc; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        k.frame_tot[2 * f + 0] = s_run_d;
+        k.frame_tot[2 * f + 1] = s_run_c;
+        if (n_hints_out) n_hints_out[f] = (long long)s_run_c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 3. glibc rand() stream (srand: vpp_core_opt.pyx:33-35; rand()%256: :93,102).
+//    y_n = x_{n+3}: y_n = y_{n-3} + y_{n-31} (mod 2^32, n >= 31), basis v_i = y_i (i<31) from
+//    srand's Schrage sequence; output o_k = y_{k+341} >> 1.  y_N = <coef(z^N mod P), v> with
+//    P(z) = z^31 - z^28 - 1.  Generator thread (frame f, block b) covers LG draws starting at
+//    k0 = rand_offset + b*LG: p = z^(rand_offset+310) * z^(b*LG) mod P gives its 31-word ring,
+//    then LG sequential steps.
+// ---------------------------------------------------------------------------------------
+struct Poly31 { u32 c[31]; };
+
+__host__ __device__ inline void poly_mulmod(const u32 *a, const u32 *b, u32 *out)
+{
+    u32 t[61];
+    for (int i = 0; i < 61; i++) t[i] = 0;
+    for (int i = 0; i < 31; i++)
+        for (int j = 0; j < 31; j++) t[i + j] += a[i] * b[j];
+    for (int kk = 60; kk >= 31; kk--) { // z^k = z^(k-3) + z^(k-31)
+        t[kk - 3] += t[kk];
+        t[kk - 31] += t[kk];
+    }
+    for (int i = 0; i < 31; i++) out[i] = t[i];
+}
+
+__device__ __forceinline__ void srand_basis(u32 seed, u32 (&v)[31])
+{
+    // glibc __srandom_r (TYPE_3): r[0]=seed (0 -> 1); r[i] = 16807*r[i-1] % 2147483647 (Schrage, int32)
+    int word = (int)(seed == 0 ? 1u : seed);
+    int r[31];
+    r[0] = word;
+#pragma unroll
+    for (int i = 1; i < 31; i++) {
+        const long long hi = word / 127773, lo = word % 127773;
+        long long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        word = (int)w;
+        r[i] = word;
+    }
+    // v_i = y_i = x_{i+3}; x_31..33 = x_0..2
+#pragma unroll
+    for (int i = 0; i < 31; i++) v[i] = (u32)r[(i + 3) % 31];
+}
+
+__global__ void __launch_bounds__(64) rand_kernel(u8 *__restrict__ out, size_t cap, const unsigned long long *__restrict__ frame_tot,
+                                                  const u32 *__restrict__ seeds, u32 seed0, Poly31 qoff,
+                                                  const u32 *__restrict__ tab /*[nblk][31]*/, int nblk)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (b >= nblk) return;
+    const unsigned long long tot = frame_tot ? frame_tot[2 * f] : (unsigned long long)cap;
+    if ((unsigned long long)b * LG >= tot) return;
+    const u32 seed = seeds ? seeds[f] : seed0 + (u32)f;
+    u32 v[31], p[31], s[31];
+    srand_basis(seed, v);
+    {
+        u32 tb[31];
+#pragma unroll
+        for (int i = 0; i < 31; i++) tb[i] = tab[(size_t)b * 31 + i];
+        // p = qoff * tb mod P
+        u32 t[61];
+#pragma unroll
+        for (int i = 0; i < 61; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 31; i++)
+#pragma unroll
+            for (int j = 0; j < 31; j++) t[i + j] += qoff.c[i] * tb[j];
+#pragma unroll
+        for (int kk = 60; kk >= 31; kk--) {
+            t[kk - 3] += t[kk];
+            t[kk - 31] += t[kk];
+        }
+#pragma unroll
+        for (int i = 0; i < 31; i++) p[i] = t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 31; i++) {
+        u32 acc = 0;
+#pragma unroll
+        for (int j = 0; j < 31; j++) acc += p[j] * v[j];
+        s[i] = acc;
+        // p = p * z mod P
+        const u32 top = p[30];
+#pragma unroll
+        for (int j = 30; j >= 1; j--) p[j] = p[j - 1];
+        p[0] = top;
+        p[28] += top;
+    }
+    // ring: slot i holds y_{n-31}, y_{n-3} is slot (i+28)%31
+    u32 *o = (u32 *)(out + (size_t)f * cap + (size_t)b * LG);
+    for (int it = 0; it < LG / 124; it++) {
+        u32 wv = 0;
+        int nb = 0, wi = 0;
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
+#pragma unroll
+            for (int i = 0; i < 31; i++) {
+                s[i] += s[(i + 28) % 31];
+                wv |= ((s[i] >> 1) & 0xFFu) << (8 * nb);
+                if (++nb == 4) {
+                    o[it * 31 + wi] = wv;
+                    wi++;
+                    wv = 0;
+                    nb = 0;
+                }
+            }
+        }
+    }
+}
+
+// full 31-bit outputs (vppx_rand_stream): same generator, int32 output
+__global__ void __launch_bounds__(64) rand_full_kernel(int *__restrict__ out, long long n, u32 seed, Poly31 qoff,
+                                                       const u32 *__restrict__ tab, int nblk)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nblk || (long long)b * LG >= n) return;
+    u32 v[31], p[31], s[31], tb[31];
+    srand_basis(seed, v);
+    for (int i = 0; i < 31; i++) tb[i] = tab[(size_t)b * 31 + i];
+    poly_mulmod(qoff.c, tb, p);
+    for (int i = 0; i < 31; i++) {
+        u32 acc = 0;
+        for (int j = 0; j < 31; j++) acc += p[j] * v[j];
+        s[i] = acc;
+        const u32 top = p[30];
+        for (int j = 30; j >= 1; j--) p[j] = p[j - 1];
+        p[0] = top;
+        p[28] += top;
+    }
+    int ri = 0;
+    for (int t = 0; t < LG; t++) {
+        s[ri] += s[(ri + 28) % 31];
+        const long long idx = (long long)b * LG + t;
+        if (idx < n) out[idx] = (int)(s[ri] >> 1);
+        ri = ri == 30 ? 0 : ri + 1;
+    }
+}
+
+// host-side tables: z^(b*LG) mod P (device resident, grown on demand) and z^N mod P
+static std::mutex g_tab_mutex;
+static std::vector<u32> g_tab_host; // [nblk][31]
+static u32 *g_tab_dev = nullptr;
+static int g_tab_dev_n = 0;
+
+static void poly_pow_z(unsigned long long N, u32 *out)
+{
+    u32 res[31] = {0}, base[31] = {0}, tmp[31];
+    res[0] = 1;
+    base[1] = 1; // z
+    while (N) {
+        if (N & 1) { poly_mulmod(res, base, tmp); memcpy(res, tmp, sizeof(tmp)); }
+        N >>= 1;
+        if (N) { poly_mulmod(base, base, tmp); memcpy(base, tmp, sizeof(tmp)); }
+    }
+    memcpy(out, res, 31 * sizeof(u32));
+}
+
+static int ensure_rand_table(vppx_ctx *ctx, int nblk, const u32 **tab_out)
+{
+    std::lock_guard<std::mutex> lk(g_tab_mutex);
+    const int have = (int)(g_tab_host.size() / 31);
+    if (have < nblk) {
+        u32 step[31];
+        poly_pow_z(LG, step);
+        g_tab_host.resize((size_t)nblk * 31);
+        if (have == 0) {
+            memset(&g_tab_host[0], 0, 31 * sizeof(u32));
+            g_tab_host[0] = 1;
+        }
+        for (int b = (have == 0 ? 1 : have); b < nblk; b++)
+            poly_mulmod(&g_tab_host[(size_t)(b - 1) * 31], step, &g_tab_host[(size_t)b * 31]);
+    }
+    if (g_tab_dev_n < nblk) {
+        // grow with slack; the old table may still be in use by enqueued kernels -> sync first
+        VPPX_HIP(hipStreamSynchronize(ctx->stream));
+        if (g_tab_dev) VPPX_HIP(hipFree(g_tab_dev));
+        g_tab_dev = nullptr;
+        g_tab_dev_n = 0;
+        VPPX_HIP(hipMalloc((void **)&g_tab_dev, (size_t)nblk * 31 * sizeof(u32)));
+        VPPX_HIP(hipMemcpy(g_tab_dev, g_tab_host.data(), (size_t)nblk * 31 * sizeof(u32), hipMemcpyHostToDevice));
+        g_tab_dev_n = nblk;
+    }
+    *tab_out = g_tab_dev;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// blend arithmetic (SURVEY A.2 / generated C of vpp_core_opt.pyx:107-124)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u8 to_u8(double v) { return (u8)(int)v; } // (uint8_t)(double): truncation
+
+// (u8)( V*cc + P*(1.0-cc) )                                   pyx:107,113,121,124
+__device__ __forceinline__ u8 blend1(u8 rv, float cc, u8 P)
+{
+    const double a = (double)__fmul_rn((float)rv, cc);
+    const double b = __dmul_rn((double)P, __dsub_rn(1.0, (double)cc));
+    return to_u8(__dadd_rn(a, b));
+}
+// (u8)( (V*cc + R*(1.0-cc)) * (1.0-beta) + R*beta )            pyx:109,116  (R*beta is float32)
+__device__ __forceinline__ u8 blend_r0(u8 rv, float cc, u8 R, float beta)
+{
+    const double a = (double)__fmul_rn((float)rv, cc);
+    const double b = __dmul_rn((double)R, __dsub_rn(1.0, (double)cc));
+    const double t = __dmul_rn(__dadd_rn(a, b), __dsub_rn(1.0, (double)beta));
+    const double u = (double)__fmul_rn((float)R, beta);
+    return to_u8(__dadd_rn(t, u));
+}
+// (u8)( (V*cc + R*(1.0-cc)) * beta + R*(1.0-beta) )            pyx:111,118
+__device__ __forceinline__ u8 blend_r1(u8 rv, float cc, u8 R, float beta)
+{
+    const double a = (double)__fmul_rn((float)rv, cc);
+    const double b = __dmul_rn((double)R, __dsub_rn(1.0, (double)cc));
+    const double t = __dmul_rn(__dadd_rn(a, b), (double)beta);
+    const double u = __dmul_rn((double)R, __dsub_rn(1.0, (double)beta));
+    return to_u8(__dadd_rn(t, u));
+}
+// (u8)( (R0*(1.0-beta) + R1*beta) * c + L*(1.0-c) )            pyx:119  (R1*beta float32)
+__device__ __forceinline__ u8 blend_l_occ(u8 R0, u8 R1, float beta, float c, u8 L)
+{
+    const double a = __dmul_rn((double)R0, __dsub_rn(1.0, (double)beta));
+    const double b = (double)__fmul_rn((float)R1, beta);
+    const double t = __dmul_rn(__dadd_rn(a, b), (double)c);
+    const double u = __dmul_rn((double)L, __dsub_rn(1.0, (double)c));
+    return to_u8(__dadd_rn(t, u));
+}
+// (u8)( Rd*c + L*(1.0-c) )                                     pyx:122  (Rd*c float32)
+__device__ __forceinline__ u8 blend_l_occ_ni(u8 Rd, float c, u8 L)
+{
+    const double a = (double)__fmul_rn((float)Rd, c);
+    const double u = __dmul_rn((double)L, __dsub_rn(1.0, (double)c));
+    return to_u8(__dadd_rn(a, u));
+}
+
+struct HintGeo {
+    int x, d0, d1, d, nk, occ, cnt;
+    float g, beta;
+    u32 base;
+};
+__device__ __forceinline__ void decode_hint(int x, float gv, u32 base, u32 flags, HintGeo &h)
+{
+    h.x = x;
+    h.g = gv;
+    h.d = (int)roundf(gv);  // round half away from zero (libc round, pyx:82)
+    h.d0 = (int)floorf(gv); // pyx:83
+    h.d1 = (int)ceilf(gv);  // pyx:84
+    h.beta = __fsub_rn(gv, (float)h.d0);
+    h.base = base;
+    h.occ = (int)(flags & 1u);
+    h.nk = (int)(signed char)((flags >> 8) & 0xFFu);
+    h.cnt = (int)(flags >> 16);
+}
+
+__device__ __forceinline__ u8 draw(const VppK &k, const u8 *rnd, const HintGeo &h, int j, int idx)
+{
+    return k.uniform ? rnd[h.base + (u32)j] : rnd[h.base + (u32)j * (u32)h.cnt + (u32)idx];
+}
+
+// Replay the chain of R pixel (yp, q) for all channels up to and including the op with key
+// (lim_y, lim_i, lim_xw, slot<=lim_slot).  R[] enters with the original pixel.
+__device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim_y, int lim_i, int lim_xw)
+{
+    const int W = k.W, H = k.H;
+    const int ylo = max(0, yp - k.n), yhi = min(min(H - 1, yp + k.n), lim_y);
+    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+    for (int yy = ylo; yy <= yhi; yy++) {
+        const size_t rowoff = ((size_t)f * H + yy) * W;
+        int cntrow = k.row_count[(size_t)f * H + yy];
+        if (yy == lim_y && lim_i + 1 < cntrow) cntrow = lim_i + 1;
+        const u8 *rnd = rnd_f + k.row_base[(size_t)f * H + yy];
+        const int yw = yp - yy;
+        for (int i = 0; i < cntrow; i++) {
+            const HintRec rec = k.rec[rowoff + i];
+            const int xd0r = rec.x - (int)floorf(rec.g);
+            const int nkq = (int)(signed char)((rec.flags >> 8) & 0xFFu);
+            // targets lie in [xd0-1-nk, xd0+nk] (or wrap -1 -> W-1)
+            if ((q < xd0r - 1 - nkq || q > xd0r + nkq) && !(q == W - 1 && xd0r - 1 - nkq < 0)) continue;
+            HintGeo h;
+            decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
+            if (yw < -h.nk || yw > h.nk) continue;
+            if (h.occ && k.discard) continue;
+            const float cc = h.occ ? k.c_occ : k.c;
+            const int xd0 = h.x - h.d0, xd1 = h.x - h.d1, xd = h.x - h.d;
+            const bool at_limit = (yy == lim_y && i == lim_i);
+            const int xw_hi = at_limit ? min(h.nk, lim_xw) : h.nk;
+            for (int xw = -h.nk; xw <= xw_hi; xw++) {
+                const int xx = h.x + xw;
+                if (xx < 0 || xx > W - 1) continue;                 // pyx:99
+                if (k.use_bil && !gate_pass(k, f, h.g, yy + yw, xx)) continue;
+                if (!(0 <= xd0 + xw && xd0 + xw <= W - 1)) continue; // pyx:104 (else-branch touches L only)
+                bool hit0, hit1 = false;
+                if (k.interp) {
+                    hit0 = (xd0 + xw == q);
+                    hit1 = (xd1 + xw >= 0) && (xd1 + xw == q);       // pyx:110,117
+                } else {
+                    const int tq = xd + xw;
+                    hit0 = ((tq < 0 ? tq + W : tq) == q);            // pyx:113,121 (wraparound)
+                }
+                if (!hit0 && !hit1) continue;
+                const int idx = k.uniform ? 0 : hint_idx(k, f, yy, h.x, h.g, h.nk, yw, xw);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j >= k.C) break;
+                    const u8 rv = draw(k, rnd, h, j, idx);
+                    if (k.interp) {
+                        if (hit0) R[j] = blend_r0(rv, cc, R[j], h.beta);
+                        if (hit1) R[j] = blend_r1(rv, cc, R[j], h.beta);
+                    } else {
+                        R[j] = blend1(rv, cc, R[j]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 5. R pixels
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yp = blockIdx.y, f = blockIdx.z;
+    if (q >= k.W) return;
+    u8 *px = k.r + (((size_t)f * k.H + yp) * k.W + q) * k.C;
+    u8 R[4] = {0, 0, 0, 0};
+    for (int j = 0; j < k.C; j++) R[j] = px[j];
+    r_chain(k, f, yp, q, R, k.H, 0x7FFFFFFF, 0x7FFFFFFF);
+    for (int j = 0; j < k.C; j++) px[j] = R[j];
+}
+
+// ---------------------------------------------------------------------------------------
+// 4. L pixels (must run BEFORE apply_r_kernel: it replays R chains from the original R)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
+{
+    const int xp = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yp = blockIdx.y, f = blockIdx.z;
+    if (xp >= k.W) return;
+    const int W = k.W, H = k.H;
+    u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
+    u8 L[4] = {0, 0, 0, 0};
+    for (int j = 0; j < k.C; j++) L[j] = px[j];
+    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+    bool touched = false;
+    for (int yy = max(0, yp - k.n); yy <= min(H - 1, yp + k.n); yy++) {
+        const size_t rowoff = ((size_t)f * H + yy) * W;
+        const int yw = yp - yy;
+        const int xa = max(0, xp - k.n), xb = min(W - 1, xp + k.n);
+        for (int s = 0; s <= xb - xa; s++) {
+            const int xx = k.direction ? xa + s : xb - s; // scan order inside the row (pyx:78,129)
+            const float gv = k.g[rowoff + xx];
+            if (!(gv > 0)) continue;
+            const uint2 dn = k.dense[rowoff + xx];
+            const HintRec rec = k.rec[rowoff + dn.x];
+            HintGeo h;
+            decode_hint(xx, gv, rec.base, rec.flags, h);
+            const int xw = xp - xx;
+            if (yw < -h.nk || yw > h.nk || xw < -h.nk || xw > h.nk) continue;
+            if (k.use_bil && !gate_pass(k, f, gv, yp, xp)) continue;
+            const u8 *rnd = rnd_f + k.row_base[(size_t)f * H + yy];
+            const int idx = k.uniform ? 0 : hint_idx(k, f, yy, xx, gv, h.nk, yw, xw);
+            const int xd0 = xx - h.d0, xd1 = xx - h.d1, xd = xx - h.d;
+            if (0 <= xd0 + xw && xd0 + xw <= W - 1) {                       // pyx:104
+                if (!h.occ) {                                                 // pyx:106-107
+                    for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]);
+                    touched = true;
+                } else if (!k.discard) {                                      // pyx:114-122
+                    if (k.interp) {
+                        const int q0 = xd0 + xw;
+                        int q1 = xd1 + xw;
+                        q1 = q1 < 0 ? q1 + W : q1;                           // unguarded read, pyx:119
+                        u8 R0[4], R1[4];
+                        const u8 *r0p = k.r + (((size_t)f * H + yp) * W + q0) * k.C;
+                        const u8 *r1p = k.r + (((size_t)f * H + yp) * W + q1) * k.C;
+                        for (int j = 0; j < 4; j++) { R0[j] = j < k.C ? r0p[j] : 0; R1[j] = j < k.C ? r1p[j] : 0; }
+                        r_chain(k, f, yp, q0, R0, yy, (int)dn.x, xw);
+                        if (q1 == q0) {
+                            for (int j = 0; j < 4; j++) R1[j] = R0[j];
+                        } else {
+                            r_chain(k, f, yp, q1, R1, yy, (int)dn.x, xw);
+                        }
+                        for (int j = 0; j < k.C; j++) L[j] = blend_l_occ(R0[j], R1[j], h.beta, k.c, L[j]);
+                    } else {
+                        int qd = xd + xw;
+                        qd = qd < 0 ? qd + W : qd;
+                        u8 Rd[4];
+                        const u8 *rdp = k.r + (((size_t)f * H + yp) * W + qd) * k.C;
+                        for (int j = 0; j < 4; j++) Rd[j] = j < k.C ? rdp[j] : 0;
+                        r_chain(k, f, yp, qd, Rd, yy, (int)dn.x, xw);
+                        for (int j = 0; j < k.C; j++) L[j] = blend_l_occ_ni(Rd[j], k.c, L[j]);
+                    }
+                    touched = true;
+                }
+            } else {                                                          // pyx:123-124
+                for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]);
+                touched = true;
+            }
+        }
+    }
+    if (touched)
+        for (int j = 0; j < k.C; j++) px[j] = L[j];
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+u64 vpp_draws_upper_bound(const VppxVppParams &p, const VppGeom &g)
+{
+    const u64 n = (u64)((p.wsize - 1) / 2);
+    const u64 per = p.uniform_color ? 1 : (2 * n + 1) * (2 * n + 1);
+    u64 ub = (u64)g.H * g.W * g.C * per;
+    ub = (ub + LG - 1) / LG * LG;
+    return ub;
+}
+
+static Poly31 qoff_for(u64 rand_offset)
+{
+    static std::mutex m;
+    static bool have0 = false;
+    static Poly31 q0;
+    Poly31 q;
+    if (rand_offset == 0) {
+        std::lock_guard<std::mutex> lk(m);
+        if (!have0) { poly_pow_z(310, q0.c); have0 = true; }
+        return q0;
+    }
+    poly_pow_z(rand_offset + 310, q.c);
+    return q;
+}
+
+int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u8 *r, const float *gmap,
+               const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev)
+{
+    if (p.method != VPPX_METHOD_RND) {
+        vppx_set_error("maxDistance colour method is not available on the device path in this build");
+        return VPPX_E_UNSUPPORTED;
+    }
+    if (g.C < 1 || g.C > 4) { vppx_set_error("channels must be 1..4 (got %d)", g.C); return VPPX_E_INVALID_ARG; }
+    if (p.wsize < 1 || p.wsize > 31) { vppx_set_error("wsize must be in 1..31 (got %d)", p.wsize); return VPPX_E_INVALID_ARG; }
+    VppK k;
+    k.B = g.B; k.H = g.H; k.W = g.W; k.C = g.C;
+    k.n = (p.wsize - 1) / 2;
+    k.direction = p.direction != 0;
+    k.uniform = p.uniform_color != 0;
+    k.discard = p.discard_occluded != 0;
+    k.interp = p.interpolate != 0;
+    k.use_dist = p.use_distance_patch != 0;
+    k.use_bil = (p.use_bilateral_patch != 0) && filled_g != nullptr;
+    k.c = p.c; k.c_occ = p.c_occ; k.dmin = p.dmin; k.dmax = p.dmax;
+    k.inv_gamma = 1.0 / p.distance_gamma;
+    k.l = l; k.r = r; k.g = gmap; k.occ = occ; k.filled = filled_g;
+    const size_t npx = (size_t)g.B * g.H * g.W;
+    int rc;
+    if ((rc = ws_get(ctx, WS_HINT_REC, npx, &k.rec))) return rc;
+    if ((rc = ws_get(ctx, WS_HINT_DENSE, npx, &k.dense))) return rc;
+    if ((rc = ws_get(ctx, WS_ROW_COUNT, (size_t)g.B * g.H, &k.row_count))) return rc;
+    if ((rc = ws_get(ctx, WS_ROW_DRAWS, (size_t)g.B * g.H, &k.row_draws))) return rc;
+    if ((rc = ws_get(ctx, WS_ROW_BASE, (size_t)g.B * g.H, &k.row_base))) return rc;
+    if ((rc = ws_get(ctx, WS_FRAME_TOT, (size_t)g.B * 2, &k.frame_tot))) return rc;
+    const u64 cap = vpp_draws_upper_bound(p, g);
+    u8 *rnd;
+    if ((rc = ws_get(ctx, WS_RAND, (size_t)g.B * cap, &rnd))) return rc;
+    k.rnd = rnd;
+    k.rnd_cap = cap;
+    const int nblk = (int)(cap / LG);
+    const u32 *tab;
+    if ((rc = ensure_rand_table(ctx, nblk, &tab))) return rc;
+
+    compact_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
+    VPPX_CHECK_LAUNCH();
+    rowscan_kernel<<<dim3(g.B), 256, 0, ctx->stream>>>(k, (long long *)n_hints_dev);
+    VPPX_CHECK_LAUNCH();
+    stage_mark(ctx, ST_VPP_COMPACT);
+    rand_kernel<<<dim3((nblk + 63) / 64, g.B), 64, 0, ctx->stream>>>(rnd, cap, k.frame_tot, seeds_dev, p.seed,
+                                                                      qoff_for(p.rand_offset), tab, nblk);
+    VPPX_CHECK_LAUNCH();
+    stage_mark(ctx, ST_VPP_RAND);
+    dim3 grid((g.W + 255) / 256, g.H, g.B);
+    apply_l_kernel<<<grid, 256, 0, ctx->stream>>>(k);
+    VPPX_CHECK_LAUNCH();
+    apply_r_kernel<<<grid, 256, 0, ctx->stream>>>(k);
+    VPPX_CHECK_LAUNCH();
+    stage_mark(ctx, ST_VPP_APPLY);
+    return 0;
+}
+
+int vpp_launch_rand_stream(vppx_ctx *ctx, u32 seed, u64 offset, int64_t n, int32_t *out_dev)
+{
+    if (n <= 0) return 0;
+    const int nblk = (int)((n + LG - 1) / LG);
+    const u32 *tab;
+    int rc;
+    if ((rc = ensure_rand_table(ctx, nblk, &tab))) return rc;
+    rand_full_kernel<<<dim3((nblk + 63) / 64), 64, 0, ctx->stream>>>(out_dev, (long long)n, seed, qoff_for(offset), tab, nblk);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// occlusion heuristic (filter.py:246-292) -> conf map (the g_occ of test.py:154)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) occ_warp_kernel(const float *__restrict__ dmap, int *__restrict__ omap_bits, int H, int W)
+{
+    // left_warp (filter.py:8-48): omap[y, x-round(d)] keeps the max on collision
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t row = ((size_t)f * H + y) * W;
+    const float v = dmap[row + x];
+    if (v > 0) {
+        const int xd = x - (int)rintf(v);
+        if (0 <= xd && xd <= W - 1) atomicMax(&omap_bits[row + xd], __float_as_int(v)); // positive floats order as ints
+    }
+}
+__global__ void __launch_bounds__(256) occ_conf_kernel(const float *__restrict__ omap, u8 *__restrict__ conf, int H, int W, int rx,
+                                                       int ry, double l, double g, double th)
+{
+    // weighted_conf (filter.py:115-164), gather form: pixel n is rejected if it is invalid, or if
+    // some valid centre c with n in c's window is nearer (larger) by more than the weighted distance
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const float *om = omap + (size_t)f * H * W;
+    const float dn = om[(size_t)y * W + x];
+    u8 cf = 0;
+    if (!(dn > 0)) {
+        cf = 1;
+    } else {
+        // centre (yc,xc) = (y - yw, x - xw) with xw in [-rx,rx], yw in [-ry-1, ry]  (asymmetric, :149)
+        for (int xw = -rx; xw <= rx && !cf; xw++)
+            for (int yw = -ry - 1; yw <= ry; yw++) {
+                const int yc = y - yw, xc = x - xw;
+                if (yc < 0 || yc > H - 1 || xc < 0 || xc > W - 1) continue;
+                const float dc = om[(size_t)yc * W + xc];
+                if (dc > 0 && dn < dc) {
+                    const double t = __dsub_rn((double)__fsub_rn(dc, dn),
+                                               __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xw)),
+                                                                      __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw)))));
+                    if (t > th) { cf = 1; break; }
+                }
+            }
+    }
+    conf[((size_t)f * H + y) * W + x] = cf;
+}
+__global__ void __launch_bounds__(256) occ_unwarp_kernel(const float *__restrict__ omap, const u8 *__restrict__ conf,
+                                                         int *__restrict__ tmp, int H, int W, double th_filter)
+{
+    // filter (filter.py:168-194) + conf_unwarp (:82-112): last writer in raster order wins
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t row = ((size_t)f * H + y) * W;
+    const float v = omap[row + x];
+    const u8 cf = conf[row + x];
+    if (v > 0 && !((double)cf > th_filter)) {
+        const int xd = x + (int)rintf(v);
+        if (0 <= xd && xd <= W - 1) atomicMax(&tmp[row + xd], (x << 1) | (int)cf);
+    }
+}
+__global__ void __launch_bounds__(256) occ_final_kernel(const int *__restrict__ tmp, u8 *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tmp[i];
+    out[i] = t < 0 ? 1 : (u8)(t & 1); // default 1 (filter.py:101)
+}
+
+int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,
+               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out)
+{
+    const size_t n = (size_t)B * H * W;
+    dim3 grid((W + 255) / 256, H, B);
+    int *tmp = nullptr;
+    int rc = ws_get(ctx, WS_LABEL, n, &tmp);
+    if (rc) return rc;
+    VPPX_HIP(hipMemsetAsync(omap, 0, n * sizeof(float), ctx->stream));
+    occ_warp_kernel<<<grid, 256, 0, ctx->stream>>>(hints, (int *)omap, H, W);
+    VPPX_CHECK_LAUNCH();
+    occ_conf_kernel<<<grid, 256, 0, ctx->stream>>>(omap, conf, H, W, rx / 2, ry / 2, l, g, th_conf);
+    VPPX_CHECK_LAUNCH();
+    VPPX_HIP(hipMemsetAsync(tmp, 0xFF, n * sizeof(int), ctx->stream));
+    occ_unwarp_kernel<<<grid, 256, 0, ctx->stream>>>(omap, conf, tmp, H, W, th_filter);
+    VPPX_CHECK_LAUNCH();
+    occ_final_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(tmp, conf_out, n);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,764 @@
+// vppx_api.hip -- C-ABI entry points of libvppx.so (declared in include/vppx.h).
+// Host-side orchestration only: context, workspace arena, H2D/D2H staging for the
+// host-pointer entry points, kernel sequencing.  No compute happens on the CPU and there is
+// no CPU fallback: without a HIP device every entry point fails with VPPX_E_NO_DEVICE.
+#include "vppx_internal.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void vppx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *vppx_last_error(void) { return g_err; }
+extern "C" int vppx_version(void) { return VPPX_VERSION; }
+
+extern "C" void vppx_vpp_params_default(VppxVppParams *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->method = VPPX_METHOD_RND;
+    p->wsize = 3;
+    p->wsize_agg_x = 64;
+    p->wsize_agg_y = 3;
+    p->direction = 1;
+    p->uniform_color = 0;
+    p->discard_occluded = 0;
+    p->interpolate = 1;
+    p->c = 0.4f;
+    p->c_occ = 0.0f;
+    p->distance_gamma = 0.3;
+    p->seed = 1;
+}
+
+extern "C" void vppx_rsgm_params_default(VppxRsgmParams *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->dmax = 192;
+    p->p1 = 11;
+    p->p2min = 17;
+    p->alpha = 0.5f;
+    p->gamma = 35;
+    p->uniqueness = 0.95f;
+    p->subpixel = 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// context / workspace
+// ---------------------------------------------------------------------------------------
+int ws_reserve(vppx_ctx *ctx, WsSlot s, size_t bytes, void **out)
+{
+    DevBuf &b = ctx->ws[s];
+    if (bytes == 0) bytes = 16;
+    if (b.cap < bytes) {
+        if (b.p) {
+            // the old buffer may still be referenced by enqueued kernels
+            VPPX_HIP(hipStreamSynchronize(ctx->stream));
+            VPPX_HIP(hipFree(b.p));
+            ctx->total_bytes -= b.cap;
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        const size_t cap = (bytes + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&b.p, cap);
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            vppx_set_error("workspace allocation of %zu bytes failed: %s", cap, hipGetErrorString(e));
+            return VPPX_E_OOM;
+        }
+        b.cap = cap;
+        ctx->total_bytes += cap;
+    }
+    *out = b.p;
+    return 0;
+}
+
+extern "C" int vppx_create(vppx_ctx **out, int device)
+{
+    if (!out) { vppx_set_error("vppx_create: out is NULL"); return VPPX_E_INVALID_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        vppx_set_error("no HIP device available (%s); libvppx has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return VPPX_E_NO_DEVICE;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev) { vppx_set_error("device %d out of range (%d devices)", device, ndev); return VPPX_E_INVALID_ARG; }
+    VPPX_HIP(hipSetDevice(device));
+    vppx_ctx *ctx = new vppx_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->devname = prop.name;
+        if (strstr(prop.gcnArchName, "gfx950") == nullptr) {
+            vppx_set_error("device %d is %s; libvppx is built for gfx950 only", device, prop.gcnArchName);
+            delete ctx;
+            return VPPX_E_NO_DEVICE;
+        }
+    }
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        vppx_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return VPPX_E_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void vppx_destroy(vppx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < WS_NUM; i++)
+        if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
+    if (ctx->ev_created)
+        for (int i = 0; i <= VPPX_MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int vppx_set_stream(vppx_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return VPPX_E_INVALID_ARG;
+    if (ctx->own_stream && ctx->stream) {
+        VPPX_HIP(hipStreamSynchronize(ctx->stream));
+        if (hip_stream != nullptr) {
+            (void)hipStreamDestroy(ctx->stream);
+            ctx->own_stream = false;
+        }
+    }
+    if (hip_stream != nullptr) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else if (!ctx->own_stream) {
+        VPPX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return 0;
+}
+
+extern "C" int vppx_synchronize(vppx_ctx *ctx)
+{
+    if (!ctx) return VPPX_E_INVALID_ARG;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" size_t vppx_workspace_bytes(const vppx_ctx *ctx) { return ctx ? ctx->total_bytes : 0; }
+extern "C" const char *vppx_device_name(const vppx_ctx *ctx) { return ctx ? ctx->devname.c_str() : ""; }
+
+// ---------------------------------------------------------------------------------------
+// stage timing
+// ---------------------------------------------------------------------------------------
+static const char *k_stage_names[ST_COUNT] = {"vpp_compact", "vpp_rand", "vpp_apply", "pad_gray", "census",
+                                              "aggregate_8paths", "sum_wta_left", "wta_right", "median_interp", "post"};
+
+extern "C" const char *vppx_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? k_stage_names[i] : ""; }
+
+extern "C" int vppx_enable_stage_timing(vppx_ctx *ctx, int enable)
+{
+    if (!ctx) return VPPX_E_INVALID_ARG;
+    if (enable && !ctx->ev_created) {
+        for (int i = 0; i <= VPPX_MAX_STAGES; i++) VPPX_HIP(hipEventCreate(&ctx->ev[i]));
+        ctx->ev_created = true;
+    }
+    ctx->stage_timing = enable != 0;
+    ctx->n_stages = 0;
+    return 0;
+}
+
+void stage_begin(vppx_ctx *ctx)
+{
+    if (!ctx->stage_timing) return;
+    ctx->n_stages = 0;
+    (void)hipEventRecord(ctx->ev[0], ctx->stream);
+}
+
+void stage_mark(vppx_ctx *ctx, int stage)
+{
+    if (!ctx->stage_timing || ctx->n_stages >= VPPX_MAX_STAGES) return;
+    ctx->stage_id[ctx->n_stages] = stage;
+    ctx->n_stages++;
+    (void)hipEventRecord(ctx->ev[ctx->n_stages], ctx->stream);
+}
+
+extern "C" int vppx_get_stage_ms(vppx_ctx *ctx, float *ms, int max_n)
+{
+    if (!ctx || !ms) return VPPX_E_INVALID_ARG;
+    for (int i = 0; i < ST_COUNT && i < max_n; i++) ms[i] = 0.f;
+    if (!ctx->stage_timing || ctx->n_stages == 0) return 0;
+    VPPX_HIP(hipEventSynchronize(ctx->ev[ctx->n_stages]));
+    for (int i = 0; i < ctx->n_stages; i++) {
+        float t = 0.f;
+        VPPX_HIP(hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]));
+        if (ctx->stage_id[i] < max_n) ms[ctx->stage_id[i]] += t;
+    }
+    return ST_COUNT < max_n ? ST_COUNT : max_n;
+}
+
+// ---------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------
+static int check_ctx(vppx_ctx *ctx)
+{
+    if (!ctx) { vppx_set_error("context is NULL (vppx_create failed? there is no CPU fallback)"); return VPPX_E_NO_DEVICE; }
+    VPPX_HIP(hipSetDevice(ctx->device));
+    return 0;
+}
+
+static int upload(vppx_ctx *ctx, WsSlot s, const void *host, size_t bytes, void **dev)
+{
+    int rc = ws_reserve(ctx, s, bytes, dev);
+    if (rc) return rc;
+    VPPX_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+static int download(vppx_ctx *ctx, void *host, const void *dev, size_t bytes)
+{
+    VPPX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+static void make_geom(int B, int H, int W, int C, int D, RsgmGeom &g)
+{
+    g.B = B; g.H = H; g.W = W; g.C = C; g.D = D;
+    const int pad_ht = (((H / 16) + 1) * 16 - H) % 16; // rsgm.py:254
+    const int pad_wd = (((W / 16) + 1) * 16 - W) % 16; // rsgm.py:255
+    g.pad_l = pad_wd / 2; g.pad_r = pad_wd - pad_wd / 2;
+    g.pad_t = pad_ht / 2; g.pad_b = pad_ht - pad_ht / 2;
+    g.Hp = H + pad_ht; g.Wp = W + pad_wd;
+}
+
+// P2(|dI|) = max(P2min, (int)(-alpha*|dI| + gamma)), float32 without contraction
+static int p2_lut_host(const VppxRsgmParams &p, u16 *lut, int *maxp2)
+{
+    int mx = 0;
+    for (int i = 0; i < 256; i++) {
+        volatile float t = (-p.alpha) * (float)i;
+        volatile float u = t + (float)p.gamma;
+        float uu = u;
+        long long v = (uu != uu) ? 0 : (uu > 2147483000.f ? 2147483647LL : (uu < -2147483000.f ? -2147483647LL : (long long)(int32_t)uu));
+        if (v < p.p2min) v = p.p2min;
+        if (v < 0) v = 0;
+        if (v > 65535) v = 65535;
+        lut[i] = (u16)v;
+        if ((int)v > mx) mx = (int)v;
+    }
+    *maxp2 = mx;
+    return 0;
+}
+
+static u32 uniq_factor(float uniqueness)
+{
+    volatile float f = 1024.0f * uniqueness;
+    return (u32)f;
+}
+
+static int check_rsgm_params(const VppxRsgmParams &p)
+{
+    // same order and messages as rsgm.py:31-35,166-167
+    if (p.dmax % 8 != 0) { vppx_set_error("Invalid dmax (%d): dmax %% 8 != 0", p.dmax); return VPPX_E_DMAX_MOD8; }
+    if (p.dmax > 256) { vppx_set_error("Invalid dmax (%d): dmax > 256", p.dmax); return VPPX_E_DMAX_GT256; }
+    if (p.dmax <= 0) { vppx_set_error("Invalid dmax (%d)", p.dmax); return VPPX_E_INVALID_ARG; }
+    if (p.uniqueness > 1.0f || p.uniqueness <= 0.0f) {
+        vppx_set_error("Invalid uniqueness (%g): uniqueness in ]0,1]", (double)p.uniqueness);
+        return VPPX_E_UNIQUENESS;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// rSGM on device buffers (core of compute_rsgm, rsgm.py:250-294)
+// ---------------------------------------------------------------------------------------
+static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, const u8 *left, const u8 *left_vpp,
+                     const u8 *right_vpp, float *disp_out)
+{
+    int rc;
+    const size_t npp = (size_t)g.B * g.Hp * g.Wp;
+    const size_t ncell = npp * g.D;
+    u8 *gl, *glv, *grv;
+    u32 *cl, *cr_raw;
+    if ((rc = ws_get(ctx, WS_GRAY_L, npp, &gl))) return rc;
+    if ((rc = ws_get(ctx, WS_GRAY_LV, npp, &glv))) return rc;
+    if ((rc = ws_get(ctx, WS_GRAY_RV, npp, &grv))) return rc;
+    if ((rc = ws_get(ctx, WS_CENSUS_L, npp, &cl))) return rc;
+    if ((rc = ws_get(ctx, WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
+    u32 *cr = cr_raw + 512;
+    if ((rc = rsgm_launch_pad_gray(ctx, g, left, gl))) return rc;
+    if ((rc = rsgm_launch_pad_gray(ctx, g, left_vpp, glv))) return rc;
+    if ((rc = rsgm_launch_pad_gray(ctx, g, right_vpp, grv))) return rc;
+    stage_mark(ctx, ST_PAD_GRAY);
+    if ((rc = rsgm_launch_census(ctx, g.B, g.Hp, g.Wp, glv, cl))) return rc;
+    if ((rc = rsgm_launch_census(ctx, g.B, g.Hp, g.Wp, grv, cr))) return rc;
+    stage_mark(ctx, ST_CENSUS);
+
+    u16 lut_h[256];
+    int maxp2;
+    p2_lut_host(p, lut_h, &maxp2);
+    u16 *lut_d;
+    if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
+    VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
+    // per-path values are bounded by Cmax + P2max (L_r - min L_r <= P2): bytes suffice when that is < 256
+    const int elem_bytes = (24 + maxp2 <= 255 && g.D % 64 == 0) ? 1 : 2;
+    void *paths;
+    if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * elem_bytes, &paths))) return rc;
+    u16 *S;
+    if ((rc = ws_get(ctx, WS_S, ncell, &S))) return rc;
+    if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes))) return rc;
+    stage_mark(ctx, ST_AGGREGATE);
+    ctx->last_B = g.B; ctx->last_Hp = g.Hp; ctx->last_Wp = g.Wp; ctx->last_D = g.D; ctx->last_rp = p; ctx->have_last = true;
+
+    float *dl0, *dl1, *dr0, *dr1;
+    if ((rc = ws_get(ctx, WS_DISP_L0, npp, &dl0))) return rc;
+    if ((rc = ws_get(ctx, WS_DISP_L1, npp, &dl1))) return rc;
+    if ((rc = ws_get(ctx, WS_DISP_R0, npp, &dr0))) return rc;
+    if ((rc = ws_get(ctx, WS_DISP_R1, npp, &dr1))) return rc;
+    const u32 fu = uniq_factor(p.uniqueness);
+    // rsgm.py:141-142: matchWTA_SSE + subPixelRefine(.., 0) are always applied to the left map
+    if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, S, dl0, fu, 1))) return rc;
+    stage_mark(ctx, ST_SUM_WTA);
+    if ((rc = rsgm_launch_wta_right(ctx, g.B, g.Hp, g.Wp, g.D, S, dr0, fu))) return rc;
+    stage_mark(ctx, ST_WTA_RIGHT);
+    if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dl0, dl1))) return rc;
+    if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dr0, dr1))) return rc;
+    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dl1))) return rc;
+    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dr1))) return rc;
+    stage_mark(ctx, ST_MEDIAN_INTERP);
+
+    const size_t np = (size_t)g.B * g.H * g.W;
+    float *fdc;
+    u8 *fd8;
+    int *label, *lcount;
+    if ((rc = ws_get(ctx, WS_FDC, np, &fdc))) return rc;
+    if ((rc = ws_get(ctx, WS_FD8, np, &fd8))) return rc;
+    if ((rc = ws_get(ctx, WS_LABEL, np, &label))) return rc;
+    if ((rc = ws_get(ctx, WS_LCOUNT, np, &lcount))) return rc;
+    if ((rc = rsgm_launch_post(ctx, g, dl1, dr1, nullptr, fdc, fd8, label, lcount, p.subpixel, disp_out))) return rc;
+    stage_mark(ctx, ST_POST);
+    return 0;
+}
+
+static int check_frames(int B, int H, int W, int C)
+{
+    if (B <= 0 || H <= 0 || W <= 0) { vppx_set_error("bad shape B=%d H=%d W=%d", B, H, W); return VPPX_E_INVALID_ARG; }
+    if (C != 1 && C != 3) { vppx_set_error("channels must be 1 or 3 (got %d)", C); return VPPX_E_INVALID_ARG; }
+    if (H < 5 || W < 5) { vppx_set_error("frame too small (%dx%d)", H, W); return VPPX_E_INVALID_ARG; }
+    return 0;
+}
+
+extern "C" int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,
+                             const uint8_t *left_vpp, const uint8_t *right_vpp, const float *hints,
+                             const float *validhints, float *disp_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!p || !left || !left_vpp || !right_vpp || !disp_out) { vppx_set_error("vppx_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_frames(B, H, W, C))) return rc;
+    if ((rc = check_rsgm_params(*p))) return rc;
+    if (hints || validhints) { vppx_set_error("--guided (_guided_dsi, rsgm.py:116) is not part of this build"); return VPPX_E_UNSUPPORTED; }
+    RsgmGeom g;
+    make_geom(B, H, W, C, p->dmax, g);
+    stage_begin(ctx);
+    return rsgm_core(ctx, *p, g, left, left_vpp, right_vpp, disp_out);
+}
+
+extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,
+                              const uint8_t *left_vpp, const uint8_t *right_vpp, const float *hints,
+                              const float *validhints, float *disp_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!p || !left || !left_vpp || !right_vpp || !disp_out) { vppx_set_error("vppx_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_frames(B, H, W, C))) return rc;
+    const size_t nb = (size_t)B * H * W * C;
+    void *dl, *dlv, *drv, *dout;
+    if ((rc = upload(ctx, WS_STAGE_A, left, nb, &dl))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_B, left_vpp, nb, &dlv))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_C, right_vpp, nb, &drv))) return rc;
+    if ((rc = ws_reserve(ctx, WS_STAGE_D, (size_t)B * H * W * sizeof(float), &dout))) return rc;
+    if ((rc = vppx_rsgm_dev(ctx, p, B, H, W, C, (const u8 *)dl, (const u8 *)dlv, (const u8 *)drv, hints, validhints, (float *)dout))) return rc;
+    if ((rc = download(ctx, disp_out, dout, (size_t)B * H * W * sizeof(float)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// VPP
+// ---------------------------------------------------------------------------------------
+static int check_vpp_params(const VppxVppParams &p)
+{
+    if (p.method != VPPX_METHOD_RND && p.method != VPPX_METHOD_MAXDIST) {
+        vppx_set_error("method must be \"rnd\" or \"maxDistance\"");
+        return VPPX_E_METHOD;
+    }
+    return 0;
+}
+
+extern "C" int vppx_vpp_dev(vppx_ctx *ctx, const VppxVppParams *p, int B, int H, int W, int C, uint8_t *l, uint8_t *r,
+                            const float *g, const uint8_t *g_occ, const float *filled_g, int64_t *n_hints_dev)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!p || !l || !r || !g) { vppx_set_error("vppx_vpp: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if (B <= 0 || H <= 0 || W <= 0) { vppx_set_error("bad shape B=%d H=%d W=%d", B, H, W); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_vpp_params(*p))) return rc;
+    VppGeom vg = {B, H, W, C};
+    stage_begin(ctx);
+    return vpp_launch(ctx, *p, vg, l, r, g, g_occ, filled_g, n_hints_dev, nullptr);
+}
+
+extern "C" int vppx_vpp_host(vppx_ctx *ctx, const VppxVppParams *p, int B, int H, int W, int C, uint8_t *l, uint8_t *r,
+                             const float *g, const uint8_t *g_occ, const float *filled_g, int64_t *n_hints)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!p || !l || !r || !g) { vppx_set_error("vppx_vpp: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if (B <= 0 || H <= 0 || W <= 0) { vppx_set_error("bad shape B=%d H=%d W=%d", B, H, W); return VPPX_E_INVALID_ARG; }
+    const size_t nb = (size_t)B * H * W * C, np = (size_t)B * H * W;
+    void *dl, *dr, *dg, *docc = nullptr, *dfg = nullptr, *dn;
+    if ((rc = upload(ctx, WS_STAGE_A, l, nb, &dl))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_B, r, nb, &dr))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_C, g, np * sizeof(float), &dg))) return rc;
+    if (g_occ && (rc = upload(ctx, WS_STAGE_D, g_occ, np, &docc))) return rc;
+    if (filled_g && (rc = upload(ctx, WS_STAGE_E, filled_g, np * sizeof(float), &dfg))) return rc;
+    if ((rc = ws_reserve(ctx, WS_NHINTS, (size_t)B * sizeof(int64_t), &dn))) return rc;
+    if ((rc = vppx_vpp_dev(ctx, p, B, H, W, C, (u8 *)dl, (u8 *)dr, (const float *)dg, (const u8 *)docc, (const float *)dfg, (int64_t *)dn))) return rc;
+    if ((rc = download(ctx, l, dl, nb))) return rc;
+    if ((rc = download(ctx, r, dr, nb))) return rc;
+    std::vector<int64_t> nh(B);
+    if ((rc = download(ctx, nh.data(), dn, (size_t)B * sizeof(int64_t)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_hints) memcpy(n_hints, nh.data(), (size_t)B * sizeof(int64_t));
+    return 0;
+}
+
+extern "C" int vppx_vpp_last_draws(vppx_ctx *ctx, int B, uint64_t *draws)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!draws || B <= 0 || !ctx->ws[WS_FRAME_TOT].p || ctx->ws[WS_FRAME_TOT].cap < (size_t)B * 16) {
+        vppx_set_error("vppx_vpp_last_draws: no VPP call with B >= %d has run", B);
+        return VPPX_E_INVALID_ARG;
+    }
+    std::vector<unsigned long long> tot((size_t)B * 2);
+    VPPX_HIP(hipMemcpyAsync(tot.data(), ctx->ws[WS_FRAME_TOT].p, tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < B; f++) draws[f] = tot[2 * f];
+    return 0;
+}
+
+extern "C" int vppx_srand(vppx_ctx *ctx, uint32_t seed)
+{
+    if (!ctx) { vppx_set_error("context is NULL"); return VPPX_E_NO_DEVICE; }
+    ctx->rnd_seed = seed;
+    ctx->rnd_consumed = 0;
+    return 0;
+}
+
+// number of rand() draws a scan consumed = what the device prefix sums computed
+static int scan_common(vppx_ctx *ctx, VppxVppParams &p, uint8_t *l, uint8_t *r, const float *g, int width, int height,
+                       int channels, const uint8_t *g_occ)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    p.seed = ctx->rnd_seed;
+    p.rand_offset = ctx->rnd_consumed;
+    int64_t nh = 0;
+    if ((rc = vppx_vpp_host(ctx, &p, 1, height, width, channels, l, r, g, g_occ, nullptr, &nh))) return rc;
+    // advance the libc-like stream by the draws this scan consumed
+    uint64_t draws = 0;
+    if ((rc = vppx_vpp_last_draws(ctx, 1, &draws))) return rc;
+    ctx->rnd_consumed += draws;
+    return (int)nh;
+}
+
+extern "C" int vppx_virtual_projection_scan_rnd(vppx_ctx *ctx, uint8_t *l, uint8_t *r, const float *g, int width,
+                                                int height, int channels, int uniform_color, int wsize, int direction,
+                                                float c, float c_occ, const uint8_t *g_occ, int discard_occluded,
+                                                int interpolate)
+{
+    VppxVppParams p;
+    vppx_vpp_params_default(&p);
+    p.method = VPPX_METHOD_RND;
+    p.uniform_color = uniform_color; p.wsize = wsize; p.direction = direction; p.c = c; p.c_occ = c_occ;
+    p.discard_occluded = discard_occluded; p.interpolate = interpolate;
+    return scan_common(ctx, p, l, r, g, width, height, channels, g_occ);
+}
+
+extern "C" int vppx_virtual_projection_scan_max_dist(vppx_ctx *ctx, uint8_t *l, uint8_t *r, const float *g, int width,
+                                                     int height, int channels, int uniform_color, int wsize,
+                                                     int wsize_agg_x, int wsize_agg_y, int direction, float c, float c_occ,
+                                                     const uint8_t *g_occ, int discard_occluded, int interpolate)
+{
+    VppxVppParams p;
+    vppx_vpp_params_default(&p);
+    p.method = VPPX_METHOD_MAXDIST;
+    p.uniform_color = uniform_color; p.wsize = wsize; p.wsize_agg_x = wsize_agg_x; p.wsize_agg_y = wsize_agg_y;
+    p.direction = direction; p.c = c; p.c_occ = c_occ;
+    p.discard_occluded = discard_occluded; p.interpolate = interpolate;
+    return scan_common(ctx, p, l, r, g, width, height, channels, g_occ);
+}
+
+extern "C" int vppx_rand_stream(vppx_ctx *ctx, uint32_t seed, uint64_t offset, int64_t n, int32_t *out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (n < 0 || (n > 0 && !out)) { vppx_set_error("vppx_rand_stream: bad arguments"); return VPPX_E_INVALID_ARG; }
+    if (n == 0) return 0;
+    void *d;
+    if ((rc = ws_reserve(ctx, WS_STAGE_A, (size_t)n * sizeof(int32_t), &d))) return rc;
+    if ((rc = vpp_launch_rand_stream(ctx, seed, offset, n, (int32_t *)d))) return rc;
+    if ((rc = download(ctx, out, d, (size_t)n * sizeof(int32_t)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused hot path (test.py:158-225): VPP -> rSGM, batched, device resident
+// ---------------------------------------------------------------------------------------
+extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W,
+                                 int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                                 uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!vp || !rp || !left || !right || !g || !disp_out) { vppx_set_error("vppx_vpp_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_frames(B, H, W, C))) return rc;
+    if ((rc = check_vpp_params(*vp))) return rc;
+    if ((rc = check_rsgm_params(*rp))) return rc;
+    const size_t nb = (size_t)B * H * W * C;
+    if (!l_vpp && (rc = ws_get(ctx, WS_VPP_L, nb, &l_vpp))) return rc;
+    if (!r_vpp && (rc = ws_get(ctx, WS_VPP_R, nb, &r_vpp))) return rc;
+    stage_begin(ctx);
+    // vpp() works on copies (np.copy, vpp_standalone.py:397)
+    VPPX_HIP(hipMemcpyAsync(l_vpp, left, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    VPPX_HIP(hipMemcpyAsync(r_vpp, right, nb, hipMemcpyDeviceToDevice, ctx->stream));
+    VppGeom vg = {B, H, W, C};
+    if ((rc = vpp_launch(ctx, *vp, vg, l_vpp, r_vpp, g, g_occ, nullptr, nullptr, nullptr))) return rc;
+    RsgmGeom rg;
+    make_geom(B, H, W, C, rp->dmax, rg);
+    return rsgm_core(ctx, *rp, rg, left, l_vpp, r_vpp, disp_out);
+}
+
+// ---------------------------------------------------------------------------------------
+// occlusion heuristic
+// ---------------------------------------------------------------------------------------
+extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,
+                                            double l, double g, double th_conf, double th_filter, uint8_t *conf_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
+    const size_t n = (size_t)B * H * W;
+    float *omap;
+    u8 *conf;
+    if ((rc = ws_get(ctx, WS_OCC_OMAP, n, &omap))) return rc;
+    if ((rc = ws_get(ctx, WS_OCC_CONF, n, &conf))) return rc;
+    return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out);
+}
+
+extern "C" int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,
+                                             double l, double g, double th_conf, double th_filter, uint8_t *conf_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
+    const size_t n = (size_t)B * H * W;
+    void *dh, *dc;
+    if ((rc = upload(ctx, WS_STAGE_A, hints, n * sizeof(float), &dh))) return rc;
+    if ((rc = ws_reserve(ctx, WS_STAGE_B, n, &dc))) return rc;
+    if ((rc = vppx_occlusion_heuristic_dev(ctx, B, H, W, (const float *)dh, rx, ry, l, g, th_conf, th_filter, (u8 *)dc))) return rc;
+    if ((rc = download(ctx, conf_out, dc, n))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// pyrSGM-compatible stage entry points (host pointers, one frame)
+// ---------------------------------------------------------------------------------------
+static int check_w16(int w)
+{
+    if (w % 16 != 0) { vppx_set_error("Invalid width (%d): width %% 16 != 0", w); return VPPX_E_WIDTH_MOD16; }
+    return 0;
+}
+static int check_dmax(int dmax)
+{
+    if (dmax % 8 != 0) { vppx_set_error("Invalid dmax (%d): dmax %% 8 != 0", dmax); return VPPX_E_DMAX_MOD8; }
+    if (dmax > 256) { vppx_set_error("Invalid dmax (%d): dmax > 256", dmax); return VPPX_E_DMAX_GT256; }
+    if (dmax <= 0) { vppx_set_error("Invalid dmax (%d)", dmax); return VPPX_E_INVALID_ARG; }
+    return 0;
+}
+
+extern "C" int vppx_census5x5(vppx_ctx *ctx, const uint8_t *img, uint32_t *out, int w, int h)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!img || !out || w <= 0 || h <= 0) { vppx_set_error("vppx_census5x5: bad arguments"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_w16(w))) return rc;
+    const size_t n = (size_t)w * h;
+    void *di, *dout;
+    if ((rc = upload(ctx, WS_STAGE_A, img, n, &di))) return rc;
+    if ((rc = ws_reserve(ctx, WS_STAGE_B, n * sizeof(u32), &dout))) return rc;
+    if ((rc = rsgm_launch_census(ctx, 1, h, w, (const u8 *)di, (u32 *)dout))) return rc;
+    if ((rc = download(ctx, out, dout, n * sizeof(u32)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int vppx_cost_census5x5_xyd(vppx_ctx *ctx, const uint32_t *cl, const uint32_t *cr, uint16_t *dsi, int w, int h,
+                                       int dmax, int n_threads_ignored)
+{
+    (void)n_threads_ignored;
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!cl || !cr || !dsi || w <= 0 || h <= 0) { vppx_set_error("vppx_cost: bad arguments"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_dmax(dmax))) return rc;
+    if ((rc = check_w16(w))) return rc;
+    const size_t n = (size_t)w * h;
+    void *dcl, *dcr, *dd;
+    if ((rc = upload(ctx, WS_STAGE_A, cl, n * sizeof(u32), &dcl))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_B, cr, n * sizeof(u32), &dcr))) return rc;
+    if ((rc = ws_reserve(ctx, WS_DSI, n * dmax * sizeof(u16), &dd))) return rc;
+    if ((rc = rsgm_launch_cost(ctx, 1, h, w, dmax, (const u32 *)dcl, (const u32 *)dcr, (u16 *)dd))) return rc;
+    if ((rc = download(ctx, dsi, dd, n * dmax * sizeof(u16)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t *dsi, uint16_t *dsi_agg, int w, int h,
+                              int dmax, int p1, int p2min, float alpha, int gamma)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!img || !dsi || !dsi_agg || w <= 0 || h <= 0) { vppx_set_error("vppx_aggregate: bad arguments"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_w16(w))) return rc; // rsgm.py:51-58 order
+    if ((rc = check_dmax(dmax))) return rc;
+    const size_t n = (size_t)w * h, nc = n * dmax;
+    VppxRsgmParams p;
+    vppx_rsgm_params_default(&p);
+    p.dmax = dmax; p.p1 = p1; p.p2min = p2min; p.alpha = alpha; p.gamma = gamma;
+    u16 lut_h[256];
+    int maxp2;
+    p2_lut_host(p, lut_h, &maxp2);
+    void *dimg, *ddsi, *paths;
+    u16 *lut_d, *S;
+    if ((rc = upload(ctx, WS_STAGE_A, img, n, &dimg))) return rc;
+    if ((rc = upload(ctx, WS_DSI, dsi, nc * sizeof(u16), &ddsi))) return rc;
+    if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
+    VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ws_reserve(ctx, WS_PATHS, nc * 8 * 2, &paths))) return rc;
+    if ((rc = ws_get(ctx, WS_S, nc, &S))) return rc;
+    if ((rc = rsgm_launch_paths(ctx, 1, h, w, dmax, (const u8 *)dimg, nullptr, nullptr, (const u16 *)ddsi, lut_d, p1, paths, 2))) return rc;
+    if ((rc = rsgm_launch_sum_wta(ctx, 1, h, w, dmax, paths, 2, S, nullptr, 0, 0))) return rc;
+    if ((rc = download(ctx, dsi_agg, S, nc * sizeof(u16)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int wta_common(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, float uniqueness, int which)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!dsi || !disp || w <= 0 || h <= 0) { vppx_set_error("vppx_match_wta: bad arguments"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_w16(w))) return rc;
+    if ((rc = check_dmax(dmax))) return rc;
+    if (which != 2 && (uniqueness > 1.0f || uniqueness <= 0.0f)) {
+        vppx_set_error("Invalid uniqueness (%g): uniqueness in ]0,1]", (double)uniqueness);
+        return VPPX_E_UNIQUENESS;
+    }
+    const size_t n = (size_t)w * h, nc = n * dmax;
+    void *dS, *dd;
+    if ((rc = upload(ctx, WS_S, dsi, nc * sizeof(u16), &dS))) return rc;
+    if (which == 2) {
+        if ((rc = upload(ctx, WS_DISP_L0, disp, n * sizeof(float), &dd))) return rc;
+        if ((rc = rsgm_launch_subpixel(ctx, 1, h, w, dmax, (const u16 *)dS, (float *)dd))) return rc;
+    } else {
+        if ((rc = ws_reserve(ctx, WS_DISP_L0, n * sizeof(float), &dd))) return rc;
+        const u32 fu = uniq_factor(uniqueness);
+        if (which == 0) rc = rsgm_launch_wta_left(ctx, 1, h, w, dmax, (const u16 *)dS, (float *)dd, fu);
+        else rc = rsgm_launch_wta_right(ctx, 1, h, w, dmax, (const u16 *)dS, (float *)dd, fu);
+        if (rc) return rc;
+    }
+    if ((rc = download(ctx, disp, dd, n * sizeof(float)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int vppx_match_wta(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, float uniqueness)
+{
+    return wta_common(ctx, dsi, disp, w, h, dmax, uniqueness, 0);
+}
+extern "C" int vppx_match_wta_right(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, float uniqueness)
+{
+    return wta_common(ctx, dsi, disp, w, h, dmax, uniqueness, 1);
+}
+extern "C" int vppx_subpixel_refine(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, int method)
+{
+    if (method != 0) return 0; // only the equiangular method is used by the reference (rsgm.py:142)
+    return wta_common(ctx, dsi, disp, w, h, dmax, 1.0f, 2);
+}
+
+extern "C" int vppx_median3x3(vppx_ctx *ctx, const float *src, float *dst, int w, int h)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!src || !dst || w <= 0 || h <= 0) { vppx_set_error("vppx_median3x3: bad arguments"); return VPPX_E_INVALID_ARG; }
+    const size_t n = (size_t)w * h;
+    void *ds, *dd;
+    if ((rc = upload(ctx, WS_DISP_L0, src, n * sizeof(float), &ds))) return rc;
+    if ((rc = ws_reserve(ctx, WS_DISP_L1, n * sizeof(float), &dd))) return rc;
+    if ((rc = rsgm_launch_median(ctx, 1, h, w, (const float *)ds, (float *)dd))) return rc;
+    if ((rc = download(ctx, dst, dd, n * sizeof(float)))) return rc;
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// measurement helper: time the dominant kernel alone with hipEvents on the launch stream
+// ---------------------------------------------------------------------------------------
+extern "C" int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!ctx->have_last || iters <= 0 || !ms_out) { vppx_set_error("vppx_time_aggregate: call vppx_rsgm_dev first"); return VPPX_E_INVALID_ARG; }
+    const VppxRsgmParams &p = ctx->last_rp;
+    u16 lut_h[256];
+    int maxp2;
+    p2_lut_host(p, lut_h, &maxp2);
+    const int elem_bytes = (24 + maxp2 <= 255 && ctx->last_D % 64 == 0) ? 1 : 2;
+    hipEvent_t e0, e1;
+    VPPX_HIP(hipEventCreate(&e0));
+    VPPX_HIP(hipEventCreate(&e1));
+    u32 *cr = (u32 *)ctx->ws[WS_CENSUS_R].p + 512;
+    VPPX_HIP(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; i++) {
+        rc = rsgm_launch_paths(ctx, ctx->last_B, ctx->last_Hp, ctx->last_Wp, ctx->last_D, (const u8 *)ctx->ws[WS_GRAY_L].p,
+                               (const u32 *)ctx->ws[WS_CENSUS_L].p, cr, nullptr, (const u16 *)ctx->ws[WS_P2LUT].p, p.p1,
+                               ctx->ws[WS_PATHS].p, elem_bytes);
+        if (rc) return rc;
+    }
+    VPPX_HIP(hipEventRecord(e1, ctx->stream));
+    VPPX_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VPPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}

@@ -1,0 +1,177 @@
+// vppx_internal.h -- shared declarations of libvppx.so (gfx950 only; not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vppx.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+void vppx_set_error(const char *fmt, ...);
+
+#define VPPX_HIP(call)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            vppx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return VPPX_E_HIP;                                                                      \
+        }                                                                                           \
+    } while (0)
+
+#define VPPX_CHECK_LAUNCH() VPPX_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------
+// workspace arena: named, grow-only device buffers owned by the context.  Everything the
+// pipeline needs between kernels lives in HBM for the lifetime of the context (288 GB:
+// batches are sized so that whole cost-path volumes stay resident).
+// ---------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum WsSlot {
+    WS_HINT_X = 0,   // compacted hint rows
+    WS_HINT_REC,
+    WS_HINT_DENSE,
+    WS_ROW_COUNT,
+    WS_ROW_DRAWS,
+    WS_ROW_BASE,
+    WS_FRAME_TOT,
+    WS_RAND,
+    WS_SEEDS,
+    WS_VPP_L,        // scratch copies of the pair (fused path)
+    WS_VPP_R,
+    WS_VPP_LSRC,
+    WS_OCC_ZERO,
+    WS_GRAY_L,       // padded gray images
+    WS_GRAY_LV,
+    WS_GRAY_RV,
+    WS_CENSUS_L,
+    WS_CENSUS_R,
+    WS_PATHS,        // 8 per-path L volumes
+    WS_S,            // aggregated volume (u16)
+    WS_DSI,          // materialised cost volume (stage API only)
+    WS_DISP_L0,
+    WS_DISP_L1,
+    WS_DISP_R0,
+    WS_DISP_R1,
+    WS_FD,
+    WS_FDC,
+    WS_FD8,
+    WS_LABEL,
+    WS_LCOUNT,
+    WS_P2LUT,
+    WS_STAGE_A,      // host-API staging (device copies of host arrays)
+    WS_STAGE_B,
+    WS_STAGE_C,
+    WS_STAGE_D,
+    WS_STAGE_E,
+    WS_STAGE_F,
+    WS_OCC_OMAP,
+    WS_OCC_CONF,
+    WS_NHINTS,
+    WS_NUM
+};
+
+#define VPPX_MAX_STAGES 24
+
+struct vppx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf ws[WS_NUM];
+    std::string devname;
+    // libc-like stream state of the single-frame scans
+    uint32_t rnd_seed = 1;
+    uint64_t rnd_consumed = 0;
+    // last rsgm geometry (for vppx_time_aggregate)
+    int last_B = 0, last_Hp = 0, last_Wp = 0, last_D = 0;
+    VppxRsgmParams last_rp;
+    bool have_last = false;
+    // stage timing
+    bool stage_timing = false;
+    int n_stages = 0;
+    hipEvent_t ev[VPPX_MAX_STAGES + 1];
+    bool ev_created = false;
+    int stage_id[VPPX_MAX_STAGES];
+    size_t total_bytes = 0;
+};
+
+int ws_reserve(vppx_ctx *ctx, WsSlot s, size_t bytes, void **out);
+template <typename T>
+static inline int ws_get(vppx_ctx *ctx, WsSlot s, size_t count, T **out)
+{
+    void *p = nullptr;
+    int rc = ws_reserve(ctx, s, count * sizeof(T), &p);
+    *out = (T *)p;
+    return rc;
+}
+
+// stage ids (vppx_stage_name)
+enum {
+    ST_VPP_COMPACT = 0,
+    ST_VPP_RAND,
+    ST_VPP_APPLY,
+    ST_PAD_GRAY,
+    ST_CENSUS,
+    ST_AGGREGATE,
+    ST_SUM_WTA,
+    ST_WTA_RIGHT,
+    ST_MEDIAN_INTERP,
+    ST_POST,
+    ST_COUNT
+};
+void stage_begin(vppx_ctx *ctx);
+void stage_mark(vppx_ctx *ctx, int stage);
+
+// ---------------------------------------------------------------------------------------
+// kernel launchers (defined in the .hip files)
+// ---------------------------------------------------------------------------------------
+struct RsgmGeom {
+    int B, H, W, C;      // input frames
+    int Hp, Wp;          // padded to multiples of 16 (rsgm.py:254-256)
+    int pad_l, pad_r, pad_t, pad_b;
+    int D;
+};
+
+// rsgm_kernels.hip
+int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gray);
+int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32 *census);
+int rsgm_launch_cost(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u32 *cl, const u32 *cr, u16 *dsi);
+// 8-path aggregation.  Cost source: census pair (dsi == nullptr) or a materialised u16 DSI.
+// Writes the 8 per-path volumes into `paths` (element size elem_bytes = 1 or 2).
+int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
+                      const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes);
+// S = sum of the 8 path volumes (+ left WTA, sub-pixel) ; disp_l may be null (stage API: S only)
+int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
+                        float *disp_l, u32 factor_uniq, int do_subpixel);
+int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
+int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp);
+int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
+int rsgm_launch_median(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, float *dst);
+int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, float *disp);
+int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
+                     float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out);
+
+// vpp_kernels.hip
+struct VppGeom {
+    int B, H, W, C;
+};
+int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u8 *r, const float *gmap,
+               const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev);
+int vpp_launch_rand_stream(vppx_ctx *ctx, u32 seed, u64 offset, int64_t n, int32_t *out_dev);
+u64 vpp_draws_upper_bound(const VppxVppParams &p, const VppGeom &g);
+
+// occ_kernels (in vpp_kernels.hip)
+int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,
+               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out);

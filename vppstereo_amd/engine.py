@@ -1,0 +1,104 @@
+"""Batched, device-resident front-end of the hot path (test.py:158-225 for B frames at once).
+
+torch is plumbing only: tensors own the HBM buffers, ``torch.cuda.current_stream`` orders the
+work, ``torch.distributed`` shards frame batches (see dist.py).  Every method hands raw device
+pointers to the C-ABI ``_dev`` entry points of libvppx.so.
+"""
+import ctypes as C
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    """One GPU's VPP+rSGM pipeline.  Inputs are CUDA tensors:
+        left, right : uint8  [B,H,W,C]     hints : float32 [B,H,W]     g_occ : uint8 [B,H,W] or None
+    """
+
+    def __init__(self, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("vppstereo_amd.Engine needs an MI355X (no CPU fallback)")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.ctx = _lib.Context(self.device.index)
+        self.lib = _lib.load()
+
+    def _bind_stream(self):
+        self.ctx.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t, dtype, ndim, name):
+        torch = self.torch
+        if t.device != self.device or t.dtype != dtype or t.dim() != ndim or not t.is_contiguous():
+            raise ValueError(f"{name}: expected contiguous {dtype} tensor with {ndim} dims on {self.device}")
+
+    def vpp(self, left, right, hints, g_occ=None, seed=1, **kw):
+        """In-place-free VPP: returns patterned copies (l_vpp, r_vpp) like vpp() does."""
+        torch = self.torch
+        self._chk(left, torch.uint8, 4, "left"); self._chk(right, torch.uint8, 4, "right")
+        self._chk(hints, torch.float32, 3, "hints")
+        B, H, W, Cc = left.shape
+        self._bind_stream()
+        l, r = left.clone(), right.clone()
+        p = _lib.vpp_params(seed=int(seed) & 0xFFFFFFFF, **kw)
+        _lib.check(self.lib.vppx_vpp_dev(self.ctx.handle, C.byref(p), B, H, W, Cc, _ptr(l), _ptr(r), _ptr(hints),
+                                         _ptr(g_occ), None, None))
+        return l, r
+
+    def rsgm(self, left, left_vpp, right_vpp, out=None, **kw):
+        torch = self.torch
+        for t, n in ((left, "left"), (left_vpp, "left_vpp"), (right_vpp, "right_vpp")):
+            self._chk(t, torch.uint8, 4, n)
+        B, H, W, Cc = left.shape
+        if out is None:
+            out = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
+        self._bind_stream()
+        p = _lib.rsgm_params(**kw)
+        _lib.check(self.lib.vppx_rsgm_dev(self.ctx.handle, C.byref(p), B, H, W, Cc, _ptr(left), _ptr(left_vpp),
+                                          _ptr(right_vpp), None, None, _ptr(out)))
+        return out
+
+    def vpp_rsgm(self, left, right, hints, g_occ=None, out=None, l_vpp=None, r_vpp=None, seed=1, vpp_kw=None,
+                 rsgm_kw=None):
+        """The whole hot path for a batch: one call, no host round trips, no synchronisation."""
+        torch = self.torch
+        self._chk(left, torch.uint8, 4, "left"); self._chk(right, torch.uint8, 4, "right")
+        self._chk(hints, torch.float32, 3, "hints")
+        B, H, W, Cc = left.shape
+        if out is None:
+            out = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
+        self._bind_stream()
+        vp = _lib.vpp_params(seed=int(seed) & 0xFFFFFFFF, **(vpp_kw or {}))
+        rp = _lib.rsgm_params(**(rsgm_kw or {}))
+        _lib.check(self.lib.vppx_vpp_rsgm_dev(self.ctx.handle, C.byref(vp), C.byref(rp), B, H, W, Cc, _ptr(left),
+                                              _ptr(right), _ptr(hints), _ptr(g_occ), _ptr(l_vpp), _ptr(r_vpp),
+                                              _ptr(out)))
+        return out
+
+    def occlusion_heuristic(self, hints, rx=9, ry=7, l=2, g=0.4375, th_conf=1, th_filter=0.1):
+        torch = self.torch
+        self._chk(hints, torch.float32, 3, "hints")
+        B, H, W = hints.shape
+        conf = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
+        self._bind_stream()
+        _lib.check(self.lib.vppx_occlusion_heuristic_dev(self.ctx.handle, B, H, W, _ptr(hints), int(rx), int(ry),
+                                                         float(l), float(g), float(th_conf), float(th_filter),
+                                                         _ptr(conf)))
+        return conf
+
+    # ---- measurement helpers (bench.py) ----
+    def time_aggregate(self, iters=10):
+        ms = C.c_float()
+        _lib.check(self.lib.vppx_time_aggregate(self.ctx.handle, int(iters), C.byref(ms)))
+        return float(ms.value)
+
+    def enable_stage_timing(self, on=True):
+        _lib.check(self.lib.vppx_enable_stage_timing(self.ctx.handle, int(bool(on))))
+
+    def stage_ms(self):
+        arr = (C.c_float * 32)()
+        n = _lib.check(self.lib.vppx_get_stage_ms(self.ctx.handle, arr, 32))
+        return {self.lib.vppx_stage_name(i).decode(): float(arr[i]) for i in range(n)}

@@ -1,0 +1,72 @@
+"""Drop-in for the reference's ``vpp_standalone.vpp`` (vpp_standalone.py:396-432).
+
+Same signature, defaults, return shapes/dtypes and error behaviour; the scans run on the
+MI355X through libvppx.so with the Cython file's arithmetic and glibc random stream (the
+parity target named by BASELINE.json; SURVEY.md A.4 lists how the numba twin differs)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def vpp(left, right, gt, wsize=3, wsizeAgg_x=64, wsizeAgg_y=3, left2right=True, blending=0.4,
+        use_distance_patch=False, use_bilateral_patch=False, distance_gamma=0.3, bilateral_o_xy=2, bilateral_o_i=1,
+        bilateral_th=.001, uniform_color=False, method="rnd", c_occ=0.00, g_occ=None, discard_occ=False,
+        interpolate=True):
+    lc, rc = np.copy(left), np.copy(right)              # :397 never mutate the arguments
+    gt = np.asarray(gt).astype(np.float32)              # :398
+
+    assert method in ["rnd", "maxDistance"]             # :400
+    direction = 1 if left2right else 0                  # :401
+
+    if len(lc.shape) < 3:                               # :403-404 gray -> [H,W,1], never squeezed
+        lc, rc = np.expand_dims(lc, axis=-1), np.expand_dims(rc, axis=-1)
+
+    if np.count_nonzero(gt) == 0:                       # :407 no projection without points
+        return lc, rc
+
+    if use_bilateral_patch:
+        raise _lib.VppxError(-10, "use_bilateral_patch (_bilateral_filling, vpp_standalone.py:372) is not part "
+                                  "of this build of the device path")
+    pos = gt[gt > 0]
+    dmin, dmax = (float(pos.min()), float(pos.max())) if pos.size else (0.0, 0.0)   # :410-411
+    if use_distance_patch and not dmax > dmin:
+        raise ZeroDivisionError("use_distance_patch needs two distinct hint values "
+                                "(vpp_standalone.py:8 divides by dmax-dmin)")
+
+    lc = np.ascontiguousarray(lc, np.uint8)
+    rc = np.ascontiguousarray(rc, np.uint8)
+    gt = np.ascontiguousarray(gt)
+    occ = None
+    if g_occ is not None:                               # :424-425 default = no occlusions
+        occ = np.ascontiguousarray(np.asarray(g_occ) != 0, np.uint8)
+    h, w, ch = lc.shape
+    lib = _lib.load()
+    ctx = _lib.default_context()
+    p = _lib.vpp_params(method=1 if method == "maxDistance" else 0, wsize=int(wsize), wsize_agg_x=int(wsizeAgg_x),
+                        wsize_agg_y=int(wsizeAgg_y), direction=direction, uniform_color=int(bool(uniform_color)),
+                        discard_occluded=int(bool(discard_occ)), interpolate=int(bool(interpolate)),
+                        c=float(blending), c_occ=float(c_occ), use_distance_patch=int(bool(use_distance_patch)),
+                        distance_gamma=float(distance_gamma), dmin=dmin, dmax=dmax)
+    # continue the libc-like stream shared with vpp_core_opt.init_rand (global state in the reference)
+    p.seed = _stream["seed"]
+    p.rand_offset = _stream["consumed"]
+    nh = (C.c_int64 * 1)()
+    _lib.check(lib.vppx_vpp_host(ctx.handle, C.byref(p), 1, h, w, ch, _lib.np_ptr(lc), _lib.np_ptr(rc),
+                                 _lib.np_ptr(gt), _lib.np_ptr(occ), None, nh))
+    draws = (C.c_uint64 * 1)()
+    _lib.check(lib.vppx_vpp_last_draws(ctx.handle, 1, draws))
+    _stream["consumed"] += int(draws[0])
+    return lc, rc
+
+
+# vpp() keeps its own (seed, draws consumed) position so that successive calls continue one
+# glibc stream, as the reference's scans do with libc's global rand() state.
+_stream = {"seed": 1, "consumed": 0}
+
+
+def init_rand(seed=0):
+    """Re-seed the stream used by vpp() (the reference seeds libc via vpp_core_opt.init_rand)."""
+    _stream["seed"] = int(seed) & 0xFFFFFFFF
+    _stream["consumed"] = 0
