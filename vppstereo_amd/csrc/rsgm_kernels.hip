@@ -229,8 +229,9 @@ struct PathArgs {
     size_t vol_elems; // elements per path volume (B*Hp*Wp*D)
 };
 
-template <int NP>
-__device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], u32 P1pk, u32 P2pk, u32 &minpk)
+template <int NP, bool EXACT>
+__device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], u32 P1pk, u32 P2pk, u32 &minpk,
+                                           const u32 (&inact)[NP])
 {
     const u32 left_in = dpp_keep<0x111>(0xFFFFFFFFu, L[NP - 1]); // row_shr:1 : lane-1's last pair
     const u32 right_in = dpp_keep<0x101>(0xFFFFFFFFu, L[0]);     // row_shl:1 : lane+1's first pair
@@ -247,6 +248,7 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], u32
         m = pk_min(m, t2);
         m = pk_adds(m, C[i]);
         Ln[i] = pk_sub(m, minpk);
+        if (!EXACT) Ln[i] |= inact[i]; // slots d >= D stay at the 0xFFFF sentinel (never the minimum)
     }
     u32 mm = Ln[0];
 #pragma unroll
@@ -356,11 +358,7 @@ __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
             di = di < 0 ? -di : di;
             P2pk = pk_splat(s_lut[di]);
         }
-        sgm_update<NP>(L, C, P1pk, P2pk, minpk);
-        if (!EXACT) {
-#pragma unroll
-            for (int i = 0; i < NP; i++) L[i] |= inact[i];
-        }
+        sgm_update<NP, EXACT>(L, C, P1pk, P2pk, minpk, inact);
         // ---- store this path's L -----------------------------------------------------------
         if (!line_active) {
             // nothing to store
