@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the VPP + rSGM hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): Mdisparities/s = frames * H * W * D / wall-seconds / 1e6 for
+VPP (rnd, reference defaults) + rSGM at 540x960, D=192, 3 % hints; inputs are resident in HBM
+when the timed region starts.  A "step" is one pass of the whole hot path (vppx_vpp_rsgm_dev)
+over one batch of B synthetic frames per GPU.  Frames shard over ranks with no data-path
+collective ("weak" scaling: B frames per GPU); the only exchange is the final gather of the
+disparity maps to rank 0, which is inside the timed region for N > 1.
+
+One JSON line is printed by rank 0.  Extra objects:
+  roofline     -- dominant kernel (8-path aggregation): algorithmic bytes per launch
+                  (10 B/cell of SURVEY 8d's 16 B/cell) / average
+                  launch duration measured with hipEvents on the launch stream, vs 8 TB/s.
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference's own
+                  rSGM natives are not in its tree) timed on this box's host cores on a
+                  bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, D, P_HINTS, C = 540, 960, 192, 0.03, 3
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+AGG_BYTES_PER_CELL = 10.0        # aggregation share of the 16 B/cell algorithmic bytes
+PATH_BYTES_PER_CELL = 16.0       # whole path, + 50 B/pixel
+PATH_BYTES_PER_PIXEL = 50.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_frames):
+    """Oracle (CPU restatement of the reference's algorithm), 1 thread, full-size frames."""
+    import oracle
+    import synth
+    t_tot = 0.0
+    for f in range(n_frames):
+        fr = synth.make_frame(H, W, D, P_HINTS, seed=1234, frame=f)
+        t0 = time.perf_counter()
+        oracle.init_rand(1 + f)
+        lv, rv = oracle.vpp(fr["left"], fr["right"], fr["hints"])
+        oracle.compute_rsgm(fr["left"], lv, rv, dmax=D, subpixel=True)
+        t_tot += time.perf_counter() - t0
+    return dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port",
+                sample=f"{n_frames} full 540x960x192 frames (VPP rnd + rSGM), oracle/liboracle.so gcc -O2, 1 thread, "
+                       f"{t_tot / n_frames:.2f} s/frame, host has {os.cpu_count()} cpus")
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import synth
+    from vppstereo_amd import dist as vdist
+    from vppstereo_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    eng = Engine(local_rank)
+
+    B = args.batch
+    n_total = B * world
+    lo, hi = vdist.shard_range(n_total, rank, world)
+    # synthetic frames: a few distinct scenes tiled over the batch (generation is host-side numpy)
+    n_unique = min(B, 4)
+    base = synth.make_batch(n_unique, H, W, D, P_HINTS, seed=1234, frame0=lo)
+    idx = [i % n_unique for i in range(B)]
+    left = torch.from_numpy(np.ascontiguousarray(base["left"][idx])).to(dev)
+    right = torch.from_numpy(np.ascontiguousarray(base["right"][idx])).to(dev)
+    hints = torch.from_numpy(np.ascontiguousarray(base["hints"][idx])).to(dev)
+    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    seed0 = vdist.frame_seed(1, lo)
+
+    def step():
+        eng.vpp_rsgm(left, right, hints, out=out, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1))
+        if world > 1 and not args.no_gather:
+            return vdist.gather_disparities(out, n_total, dst=0)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total * H * W * D * args.steps / dt / 1e6
+
+    result = None
+    if rank == 0:
+        # ---- dominant kernel, measured live with hipEvents on its own launch stream ----------
+        agg_ms = eng.time_aggregate(iters=max(3, min(10, args.steps)))
+        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+        cells_launch = B * Hp * Wp * D
+        achieved = cells_launch * AGG_BYTES_PER_CELL / (agg_ms * 1e-3) / 1e9
+        eng.enable_stage_timing(True)
+        step()
+        torch.cuda.synchronize()
+        stages = eng.stage_ms()
+        eng.enable_stage_timing(False)
+        pipeline_gbs = value * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / D) / 1e9
+        result = {
+            "metric": "Mdisparities/s (HxWxD / s) VPP+rSGM at 540x960xD=192",
+            "value": round(value, 1), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": f"540x960 RGB pair, 3% hints, VPP(rnd, wsize 3)+rSGM D=192 subpixel, "
+                                   f"{B} frames/GPU/step resident in HBM", "frames_per_step": n_total,
+                       "H": H, "W": W, "D": D, "hint_density": P_HINTS},
+            "roofline": {"bound": "hbm", "kernel": "sgm_paths_kernel (8-path aggregation)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(agg_ms, 4), "bytes_per_cell": AGG_BYTES_PER_CELL,
+                         "cells_per_launch": cells_launch},
+            "pipeline_roofline": {"bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,
+                                  "achieved_GBps": round(pipeline_gbs, 1),
+                                  "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4)},
+            "stage_ms": {k: round(v, 3) for k, v in stages.items()},
+            "device": eng.ctx.device_name,
+        }
+        if world == 1 and args.cpu_frames > 0:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+            result["speedup_vs_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -766,51 +766,48 @@ int rsgm_launch_median(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, f
 
 // ---------------------------------------------------------------------------------------
 // _linear_interpolate(dmap, 15, 3) (rsgm.py:67-113) + np.clip(.,0,None) (:151,179).
-// In place and raster-sequential in the reference (a fill rewrites the two end points that
-// the next gap reads), so each row is one sequential chain: one wave per row, the row lives
-// in LDS, lane 0 walks it.  O(Hp) parallel chains per frame; cost is a few microseconds.
+// The reference walks each row in place.  A fill only happens for a gap (maximal run of
+// values <= 0 between two valid pixels xl < xr of the same row) with xr-xl <= 14, and it is
+// triggered by the first hole pixel, in raster order, that sees both ends inside its +-7
+// window: x_t = max(xl+1, xr-7).  The line (m, q) is formed in float64 relative to x_t and
+// every pixel of [xl, xr] is overwritten with (float)(m*(x-x_t)+q); the two end points come
+// back bit-identical (the float64 error is far below half a float32 ulp), so gaps are
+// independent and every hole pixel can evaluate its own value: one thread per pixel.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) linear_interp_clip_kernel(float *__restrict__ disp, int Hp, int Wp)
+__global__ void __launch_bounds__(256) linear_interp_clip_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                 int Hp, int Wp)
 {
-    extern __shared__ __attribute__((aligned(16))) float row[];
-    const int y = blockIdx.x, f = blockIdx.y;
-    float *g = disp + ((size_t)f * Hp + y) * Wp;
-    for (int x = threadIdx.x; x < Wp; x += 64) row[x] = g[x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int n = 15 / 2;
-        for (int x = 0; x < Wp; x++) {
-            if (row[x] <= 0) {
-                double n_left = 0, n_right = 0;
-                int n_leftx = 0, n_rightx = 0;
-                for (int xw = -1; xw > -n - 1; xw--)
-                    if (0 <= x + xw && x + xw < Wp && row[x + xw] > 0) {
-                        n_left = (double)row[x + xw]; n_leftx = xw; break;
-                    }
-                for (int xw = 1; xw < n + 1; xw++)
-                    if (0 <= x + xw && x + xw < Wp && row[x + xw] > 0) {
-                        n_right = (double)row[x + xw]; n_rightx = xw; break;
-                    }
-                if (n_left > 0 && n_right > 0 && fabs(n_left - n_right) < 3.0) {
-                    const double m = __ddiv_rn(n_right - n_left, (double)(n_rightx - n_leftx));
-                    const double q = __dsub_rn(n_left, __dmul_rn(m, (double)n_leftx));
-                    for (int xw = n_leftx; xw < n_rightx + 1; xw++)
-                        row[x + xw] = (float)__dadd_rn(__dmul_rn(m, (double)xw), q);
-                }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= Wp) return;
+    const float *row = src + ((size_t)f * Hp + y) * Wp;
+    float v = row[x];
+    if (v <= 0) {
+        int xl = -1, xr = -1;
+        for (int k = 1; k <= 13; k++)
+            if (x - k >= 0 && row[x - k] > 0) { xl = x - k; break; }
+        if (xl >= 0) {
+            for (int k = 1; k <= 14 - (x - xl); k++)
+                if (x + k < Wp && row[x + k] > 0) { xr = x + k; break; }
+        }
+        if (xl >= 0 && xr >= 0) { // xr - xl <= 14 by construction
+            const double n_left = (double)row[xl], n_right = (double)row[xr];
+            if (fabs(n_left - n_right) < 3.0) {
+                const int xt = max(xl + 1, xr - 7);
+                const int n_leftx = xl - xt, n_rightx = xr - xt;
+                const double m = __ddiv_rn(n_right - n_left, (double)(n_rightx - n_leftx));
+                const double q = __dsub_rn(n_left, __dmul_rn(m, (double)n_leftx));
+                v = (float)__dadd_rn(__dmul_rn(m, (double)(x - xt)), q);
             }
         }
     }
-    __syncthreads();
-    for (int x = threadIdx.x; x < Wp; x += 64) {
-        const float v = row[x];
-        g[x] = (v >= 0) ? v : 0.0f; // np.clip(., 0, None); NaN cannot occur
-    }
+    dst[((size_t)f * Hp + y) * Wp + x] = (v >= 0) ? v : 0.0f; // np.clip(., 0, None)
 }
 
-int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, float *disp)
+int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, float *dst)
 {
-    dim3 grid(Hp, B);
-    linear_interp_clip_kernel<<<grid, 64, (size_t)Wp * sizeof(float), ctx->stream>>>(disp, Hp, Wp);
+    dim3 grid((Wp + 255) / 256, Hp, B);
+    linear_interp_clip_kernel<<<grid, 256, 0, ctx->stream>>>(src, dst, Hp, Wp);
     VPPX_CHECK_LAUNCH();
     return 0;
 }
@@ -821,8 +818,8 @@ int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, float *
 //   (0,200,10) -> astype(float32) -> restore sub-pixel -> _interpolate_background (:185-227)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) crop_lrc_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
-                                                       float *__restrict__ fdc, u8 *__restrict__ fd8, int *__restrict__ label,
-                                                       int H, int W, int Hp, int Wp, int pad_t, int pad_l)
+                                                       float *__restrict__ fdc, u8 *__restrict__ fd8, int H, int W, int Hp,
+                                                       int Wp, int pad_t, int pad_l)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, f = blockIdx.z;
@@ -844,10 +841,16 @@ __global__ void __launch_bounds__(256) crop_lrc_kernel(const float *__restrict__
     const size_t o = ((size_t)f * H + y) * W + x;
     fdc[o] = v;
     fd8[o] = (u8)keep; // astype(np.uint8): truncation, values in [0,256)
-    label[o] = (int)((size_t)y * W + x);
 }
 
-// union-find connected components (4-connectivity, |a-b| <= maxDiff, pixels == newVal excluded)
+// Connected components for cv2.filterSpeckles (4-connectivity, |a-b| <= maxDiff, pixels equal
+// to newVal excluded), run-based union-find:
+//   runs   : every pixel gets the index of the first pixel of its horizontal run (segmented
+//            max-scan per row); the run's last pixel stores the run length at the run start
+//   vunion : one union per place where a vertical link begins (not one per pixel)
+//   count  : one atomicAdd(run length) per run on the component root (a giant component would
+//            otherwise serialise half a million atomics on one address)
+//   apply  : components with <= maxSpeckleSize pixels are set to newVal
 __device__ __forceinline__ int uf_find(int *label, int i)
 {
     int p = label[i];
@@ -869,40 +872,89 @@ __device__ __forceinline__ void uf_union(int *label, int a, int b)
         a = old;
     }
 }
-__global__ void __launch_bounds__(256) speckle_union_kernel(const u8 *__restrict__ img, int *__restrict__ label, int H, int W,
-                                                            int new_val, int max_diff)
+__device__ __forceinline__ bool px_link(int a, int b, int new_val, int max_diff)
+{
+    return a != new_val && b != new_val && abs(a - b) <= max_diff;
+}
+
+__global__ void __launch_bounds__(256) speckle_runs_kernel(const u8 *__restrict__ img, int *__restrict__ label,
+                                                           int *__restrict__ runlen, int H, int W, int new_val, int max_diff)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_carry;
+    const int y = blockIdx.x, f = blockIdx.y;
+    const size_t base = ((size_t)f * H + y) * W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = -1;
+    __syncthreads();
+    for (int x0 = 0; x0 < W; x0 += 256) {
+        const int x = x0 + threadIdx.x;
+        int v = new_val, vprev = new_val, vnext = new_val;
+        if (x < W) {
+            v = img[base + x];
+            if (x > 0) vprev = img[base + x - 1];
+            if (x + 1 < W) vnext = img[base + x + 1];
+        }
+        const bool inside = x < W && v != new_val;
+        const bool start = inside && !(x > 0 && px_link(vprev, v, new_val, max_diff));
+        int s = start ? x : -1; // inclusive max-scan of run starts
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(s, off);
+            if (lane >= off) s = max(s, t);
+        }
+        if (lane == 63) s_w[wv] = s;
+        __syncthreads();
+        int pre = s_carry;
+        for (int w = 0; w < wv; w++) pre = max(pre, s_w[w]);
+        s = max(s, pre);
+        if (inside) {
+            label[base + x] = y * W + s;
+            const bool end = !(x + 1 < W && px_link(v, vnext, new_val, max_diff));
+            if (end) runlen[base + s] = x - s + 1;
+        } else if (x < W) {
+            label[base + x] = -1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = s;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) speckle_vunion_kernel(const u8 *__restrict__ img, int *__restrict__ label, int H, int W,
+                                                             int new_val, int max_diff)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, f = blockIdx.z;
-    if (x >= W) return;
+    if (x >= W || y + 1 >= H) return;
     const u8 *im = img + (size_t)f * H * W;
     int *lb = label + (size_t)f * H * W;
     const int i = y * W + x;
-    const int v = im[i];
-    if (v == new_val) return;
-    if (x + 1 < W) {
-        const int u = im[i + 1];
-        if (u != new_val && abs(v - u) <= max_diff) uf_union(lb, i, i + 1);
+    const int a = im[i], b = im[i + W];
+    if (!px_link(a, b, new_val, max_diff)) return;
+    // skip when the pixel to the left carries the same vertical link between the same two runs
+    if (x > 0) {
+        const int a0 = im[i - 1], b0 = im[i + W - 1];
+        if (px_link(a0, b0, new_val, max_diff) && px_link(a0, a, new_val, max_diff) && px_link(b0, b, new_val, max_diff)) return;
     }
-    if (y + 1 < H) {
-        const int u = im[i + W];
-        if (u != new_val && abs(v - u) <= max_diff) uf_union(lb, i, i + W);
-    }
+    uf_union(lb, lb[i], lb[i + W]);
 }
-__global__ void __launch_bounds__(256) speckle_count_kernel(const u8 *__restrict__ img, int *__restrict__ label,
-                                                            int *__restrict__ count, int H, int W, int new_val)
+
+__global__ void __launch_bounds__(256) speckle_count_kernel(int *__restrict__ label, const int *__restrict__ runlen,
+                                                            int *__restrict__ count, int H, int W)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, f = blockIdx.z;
     if (x >= W) return;
     const size_t base = (size_t)f * H * W;
     const int i = y * W + x;
-    if (img[base + i] == new_val) return;
+    // run starts are the only pixels with a run length (runlen is zeroed before every call)
+    if (runlen[base + i] <= 0) return;
     const int r = uf_find(label + base, i);
-    label[base + i] = r; // flatten (roots are fixed points, so concurrent flattening is benign)
-    atomicAdd(&count[base + r], 1);
+    atomicAdd(&count[base + r], runlen[base + i]);
 }
-__global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict__ fd8, const int *__restrict__ label,
+
+__global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict__ fd8, int *__restrict__ label,
                                                             const int *__restrict__ count, const float *__restrict__ fdc,
                                                             float *__restrict__ out, int H, int W, int new_val, int max_size,
                                                             int subpixel)
@@ -913,7 +965,8 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict
     const size_t o = ((size_t)f * H + y) * W + x;
     int v = fd8[o];
     if (v != new_val) {
-        const int r = uf_find((int *)label + (size_t)f * H * W, y * W + x);
+        int *lb = label + (size_t)f * H * W;
+        const int r = uf_find(lb, lb[y * W + x]);
         if (count[(size_t)f * H * W + r] <= max_size) v = new_val;
     }
     float fv = (float)v;                       // rsgm.py:286
@@ -921,86 +974,99 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict
     out[o] = fv;
 }
 
-// _interpolate_background rows (rsgm.py:189-214): one thread per row, row staged in LDS by the wave
-__global__ void __launch_bounds__(64) interp_bg_rows_kernel(float *__restrict__ dm, int H, int W)
+// _interpolate_background rows (rsgm.py:189-214).  Fills only touch invalid (<= 0) pixels and
+// read only originally valid ones, so per pixel: nearest valid to the left (xl) and to the
+// right (xr) of the ORIGINAL row; both -> min(v[xl], v[xr]); only one -> that one (border
+// extension); none -> unchanged.  Nearest-valid indices by Hillis-Steele max/min scans in LDS.
+__global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__ dm, int H, int W)
 {
-    extern __shared__ __attribute__((aligned(16))) float row[];
+    extern __shared__ __attribute__((aligned(16))) int sh[]; // [2][W] nearest-valid indices, then [W] floats
+    int *il = sh, *ir = sh + W;
+    float *val = (float *)(sh + 2 * W);
     const int y = blockIdx.x, f = blockIdx.y;
     float *g = dm + ((size_t)f * H + y) * W;
-    for (int x = threadIdx.x; x < W; x += 64) row[x] = g[x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int count = 0;
-        for (int u = 0; u < W; u++) {
-            if (row[u] > 0) {
-                if (count >= 1) {
-                    const int u1 = u - count, u2 = u - 1;
-                    if (u1 > 0 && u2 < W - 1) {
-                        const float a = row[u1 - 1], b = row[u2 + 1];
-                        const float d_ipol = b < a ? b : a;
-                        for (int uc = u1; uc <= u2; uc++) row[uc] = d_ipol;
-                    }
-                }
-                count = 0;
-            } else {
-                count++;
-            }
-        }
-        for (int u = 0; u < W; u++)
-            if (row[u] > 0) {
-                for (int u2 = 0; u2 < u; u2++) row[u2] = row[u];
-                break;
-            }
-        for (int u = W - 1; u >= 0; u--)
-            if (row[u] > 0) {
-                for (int u2 = u + 1; u2 < W; u2++) row[u2] = row[u];
-                break;
-            }
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const float v = g[x];
+        val[x] = v;
+        il[x] = v > 0 ? x : -1;
+        ir[x] = v > 0 ? x : 0x7FFFFFFF;
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 64) g[x] = row[x];
+    for (int s = 1; s < W; s <<= 1) {
+        int tl[8], tr[8]; // W <= 2048 with 256 threads
+        int k = 0;
+        for (int x = threadIdx.x; x < W; x += 256, k++) {
+            tl[k] = x - s >= 0 ? max(il[x], il[x - s]) : il[x];
+            tr[k] = x + s < W ? min(ir[x], ir[x + s]) : ir[x];
+        }
+        __syncthreads();
+        k = 0;
+        for (int x = threadIdx.x; x < W; x += 256, k++) { il[x] = tl[k]; ir[x] = tr[k]; }
+        __syncthreads();
+    }
+    for (int x = threadIdx.x; x < W; x += 256) {
+        float v = val[x];
+        if (!(v > 0)) {
+            const int xl = il[x], xr = ir[x];
+            const bool hl = xl >= 0, hr = xr < W;
+            if (hl && hr) {
+                const float a = val[xl], b = val[xr];
+                v = b < a ? b : a; // Python min(a, b)
+            } else if (hr) {
+                v = val[xr];
+            } else if (hl) {
+                v = val[xl];
+            }
+            g[x] = v;
+        }
+    }
 }
-// columns (rsgm.py:216-227): one thread per column (coalesced across threads)
+// columns (rsgm.py:216-227): per column, rows above the first valid row take its value, rows
+// below the last valid row take that one's.  Block = 64 columns x 4 row-lanes.
 __global__ void __launch_bounds__(256) interp_bg_cols_kernel(float *__restrict__ dm, int H, int W)
 {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_first[4][64], s_last[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int u = blockIdx.x * 64 + cx;
     const int f = blockIdx.y;
-    if (u >= W) return;
     float *g = dm + (size_t)f * H * W;
-    int first = -1, last = -1;
-    for (int v = 0; v < H; v++)
-        if (g[(size_t)v * W + u] > 0) { first = v; break; }
-    if (first < 0) return;
-    {
-        const float fv = g[(size_t)first * W + u];
-        for (int v2 = 0; v2 < first; v2++) g[(size_t)v2 * W + u] = fv;
-    }
-    for (int v = H - 1; v >= 0; v--)
-        if (g[(size_t)v * W + u] > 0) { last = v; break; }
-    {
-        const float lv = g[(size_t)last * W + u];
-        for (int v2 = last + 1; v2 < H; v2++) g[(size_t)v2 * W + u] = lv;
-    }
+    int first = 0x7FFFFFFF, last = -1;
+    if (u < W)
+        for (int v = ry; v < H; v += 4)
+            if (g[(size_t)v * W + u] > 0) { first = min(first, v); last = max(last, v); }
+    s_first[ry][cx] = first;
+    s_last[ry][cx] = last;
+    __syncthreads();
+    first = min(min(s_first[0][cx], s_first[1][cx]), min(s_first[2][cx], s_first[3][cx]));
+    last = max(max(s_last[0][cx], s_last[1][cx]), max(s_last[2][cx], s_last[3][cx]));
+    if (u >= W || last < 0) return;
+    const float fv = g[(size_t)first * W + u], lv = g[(size_t)last * W + u];
+    for (int v = ry; v < first; v += 4) g[(size_t)v * W + u] = fv;
+    for (int v = last + 1 + ry; v < H; v += 4) g[(size_t)v * W + u] = lv;
 }
 
 int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
                      float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out)
 {
-    (void)fd;
+    int *runlen = (int *)fd; // scratch [B*H*W] ints
     dim3 grid((g.W + 255) / 256, g.H, g.B);
     const size_t n = (size_t)g.B * g.H * g.W;
-    crop_lrc_kernel<<<grid, 256, 0, ctx->stream>>>(dl_pad, dr_pad, fdc, fd8, label, g.H, g.W, g.Hp, g.Wp, g.pad_t, g.pad_l);
+    if (g.W > 2048) { vppx_set_error("frame width %d > 2048 is not supported by the post-processing kernels", g.W); return VPPX_E_UNSUPPORTED; }
+    crop_lrc_kernel<<<grid, 256, 0, ctx->stream>>>(dl_pad, dr_pad, fdc, fd8, g.H, g.W, g.Hp, g.Wp, g.pad_t, g.pad_l);
     VPPX_CHECK_LAUNCH();
     VPPX_HIP(hipMemsetAsync(lcount, 0, n * sizeof(int), ctx->stream));
-    speckle_union_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, g.H, g.W, 0, 10);
+    VPPX_HIP(hipMemsetAsync(runlen, 0, n * sizeof(int), ctx->stream));
+    speckle_runs_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(fd8, label, runlen, g.H, g.W, 0, 10);
     VPPX_CHECK_LAUNCH();
-    speckle_count_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, lcount, g.H, g.W, 0);
+    speckle_vunion_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, g.H, g.W, 0, 10);
+    VPPX_CHECK_LAUNCH();
+    speckle_count_kernel<<<grid, 256, 0, ctx->stream>>>(label, runlen, lcount, g.H, g.W);
     VPPX_CHECK_LAUNCH();
     speckle_apply_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, lcount, fdc, out, g.H, g.W, 0, 200, subpixel);
     VPPX_CHECK_LAUNCH();
-    interp_bg_rows_kernel<<<dim3(g.H, g.B), 64, (size_t)g.W * sizeof(float), ctx->stream>>>(out, g.H, g.W);
+    interp_bg_rows_kernel<<<dim3(g.H, g.B), 256, (size_t)g.W * 3 * sizeof(int), ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();
-    interp_bg_cols_kernel<<<dim3((g.W + 255) / 256, g.B), 256, 0, ctx->stream>>>(out, g.H, g.W);
+    interp_bg_cols_kernel<<<dim3((g.W + 63) / 64, g.B), 256, 0, ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();
     return 0;
 }

@@ -337,19 +337,20 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     stage_mark(ctx, ST_WTA_RIGHT);
     if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dl0, dl1))) return rc;
     if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dr0, dr1))) return rc;
-    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dl1))) return rc;
-    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dr1))) return rc;
+    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dl1, dl0))) return rc;
+    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dr1, dr0))) return rc;
     stage_mark(ctx, ST_MEDIAN_INTERP);
 
     const size_t np = (size_t)g.B * g.H * g.W;
-    float *fdc;
+    float *fdc, *fdscr;
     u8 *fd8;
     int *label, *lcount;
+    if ((rc = ws_get(ctx, WS_FD, np, &fdscr))) return rc;
     if ((rc = ws_get(ctx, WS_FDC, np, &fdc))) return rc;
     if ((rc = ws_get(ctx, WS_FD8, np, &fd8))) return rc;
     if ((rc = ws_get(ctx, WS_LABEL, np, &label))) return rc;
     if ((rc = ws_get(ctx, WS_LCOUNT, np, &lcount))) return rc;
-    if ((rc = rsgm_launch_post(ctx, g, dl1, dr1, nullptr, fdc, fd8, label, lcount, p.subpixel, disp_out))) return rc;
+    if ((rc = rsgm_launch_post(ctx, g, dl0, dr0, fdscr, fdc, fd8, label, lcount, p.subpixel, disp_out))) return rc;
     stage_mark(ctx, ST_POST);
     return 0;
 }

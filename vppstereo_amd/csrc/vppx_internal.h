@@ -159,7 +159,7 @@ int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 
 int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp);
 int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
 int rsgm_launch_median(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, float *dst);
-int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, float *disp);
+int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, float *dst);
 int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
                      float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out);
 
