@@ -18,6 +18,8 @@
 // plus four DPP row_ror steps.  One wave therefore advances 4 scan lines at once.
 #include "vppx_internal.h"
 
+#include <stdlib.h>
+
 #define INVALID_DISP_COST 16u
 #define INVALID_DISP (-10.0f)
 
@@ -51,12 +53,17 @@ __device__ __forceinline__ u32 dpp_keep(u32 old, u32 src)
 {
     return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
 }
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_ror(u32 src) // row_ror has no invalid lanes: bound_ctrl lets it fold into the VALU op
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xF, 0xF, true);
+}
 __device__ __forceinline__ u32 row_min_u32(u32 v)
 {
-    v = min(v, dpp_keep<0x128>(v, v)); // row_ror:8
-    v = min(v, dpp_keep<0x124>(v, v)); // row_ror:4
-    v = min(v, dpp_keep<0x122>(v, v)); // row_ror:2
-    v = min(v, dpp_keep<0x121>(v, v)); // row_ror:1
+    v = min(v, dpp_ror<0x128>(v)); // row_ror:8
+    v = min(v, dpp_ror<0x124>(v)); // row_ror:4
+    v = min(v, dpp_ror<0x122>(v)); // row_ror:2
+    v = min(v, dpp_ror<0x121>(v)); // row_ror:1
     return v;
 }
 __device__ __forceinline__ u32 row_or_u32(u32 v)
@@ -226,58 +233,275 @@ struct PathArgs {
     const u16 *p2lut;
     void *out;
     int Hp, Wp, D, p1;
+    int B, nlb;       // frames, line blocks (16 lines each) per direction
     size_t vol_elems; // elements per path volume (B*Hp*Wp*D)
 };
 
-template <int NP, bool EXACT>
-__device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], u32 P1pk, u32 P2pk, u32 &minpk,
-                                           const u32 (&inact)[NP])
+// min over the GW lanes that own one pixel (GW = 4, 8 or 16); every lane ends up with it
+template <int GW>
+__device__ __forceinline__ u32 grp_min_u32(u32 v)
 {
-    const u32 left_in = dpp_keep<0x111>(0xFFFFFFFFu, L[NP - 1]); // row_shr:1 : lane-1's last pair
-    const u32 right_in = dpp_keep<0x101>(0xFFFFFFFFu, L[0]);     // row_shl:1 : lane+1's first pair
+    v = min(v, dpp_ror<0xB1>(v)); // quad_perm [1,0,3,2]
+    v = min(v, dpp_ror<0x4E>(v)); // quad_perm [2,3,0,1]
+    if (GW >= 8) v = min(v, dpp_ror<0x141>(v));  // row_half_mirror
+    if (GW >= 16) v = min(v, dpp_ror<0x140>(v)); // row_mirror
+    return v;
+}
+
+// One min-plus step for NP packed pairs per lane.  `first`/`last` tell whether this lane holds
+// the lowest / highest disparities of its pixel (d-1 of the first and d+1 of the last do not
+// exist: 0xFFFF sentinel).  The work is written stage by stage across all pairs: gfx950 needs a
+// wait state between a packed (VOP3P) op and a consumer of its result, so NP independent chains
+// are kept side by side instead of one dependent chain after the other.
+// FUSE: the matching cost is added with v_bcnt_u32_b32's free accumulator (plain add); only
+// used by the byte-volume variant, where nothing can saturate.  X0/X1 = cl ^ cr words.
+template <int NP, bool EXACT, int GW, bool FUSE>
+__device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], const u32 (&X0)[NP], const u32 (&X1)[NP],
+                                           u32 P1pk, u32 P2pk, u32 &minpk, const u32 (&inact)[NP], bool first, bool last)
+{
+    u32 left_in = dpp_keep<0x111>(0xFFFFFFFFu, L[NP - 1]); // row_shr:1 : lane-1's last pair
+    u32 right_in = dpp_keep<0x101>(0xFFFFFFFFu, L[0]);     // row_shl:1 : lane+1's first pair
+    if (GW < 16) {
+        left_in = first ? 0xFFFFFFFFu : left_in;
+        right_in = last ? 0xFFFFFFFFu : right_in;
+    }
     const u32 t2 = pk_adds(minpk, P2pk);
-    u32 Ln[NP];
+    u32 al[NP + 1]; // al[i] = {L[2i-1], L[2i]}
+    al[0] = __builtin_amdgcn_alignbit(L[0], left_in, 16);
+#pragma unroll
+    for (int i = 1; i < NP; i++) al[i] = __builtin_amdgcn_alignbit(L[i], L[i - 1], 16);
+    al[NP] = __builtin_amdgcn_alignbit(right_in, L[NP - 1], 16);
+    u32 m[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_min(al[i], al[i + 1]);
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_adds(m[i], P1pk);
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], L[i]);
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], t2);
+    if (FUSE) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) m[i] = m[i] + (u32)__popc(X0[i]) + ((u32)__popc(X1[i]) << 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; i++) m[i] = pk_adds(m[i], C[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        const u32 prevp = (i == 0) ? left_in : L[i - 1];
-        const u32 nextp = (i == NP - 1) ? right_in : L[i + 1];
-        const u32 dm1 = __builtin_amdgcn_alignbit(L[i], prevp, 16);  // {L[2i-1], L[2i]}
-        const u32 dp1 = __builtin_amdgcn_alignbit(nextp, L[i], 16);  // {L[2i+1], L[2i+2]}
-        u32 m = pk_adds(pk_min(dm1, dp1), P1pk);
-        m = pk_min(m, L[i]);
-        m = pk_min(m, t2);
-        m = pk_adds(m, C[i]);
-        Ln[i] = pk_sub(m, minpk);
-        if (!EXACT) Ln[i] |= inact[i]; // slots d >= D stay at the 0xFFFF sentinel (never the minimum)
+        m[i] = pk_sub(m[i], minpk);
+        if (!EXACT) m[i] |= inact[i]; // slots d >= D stay at the 0xFFFF sentinel (never the minimum)
+        L[i] = m[i];
     }
-    u32 mm = Ln[0];
+    // min over this lane's pairs as a balanced tree, then across the pixel's lanes
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-        L[i] = Ln[i];
-        mm = pk_min(mm, Ln[i]);
-    }
-    mm = min(mm & 0xFFFFu, mm >> 16);
-    mm = row_min_u32(mm);
+    for (int w = 1; w < NP; w <<= 1)
+#pragma unroll
+        for (int i = 0; i + w < NP; i += 2 * w) m[i] = pk_min(m[i], m[i + w]);
+    u32 mm = min(m[0] & 0xFFFFu, m[0] >> 16);
+    mm = grp_min_u32<GW>(mm);
     minpk = pk_splat(mm);
 }
 
-template <int DPL, bool EXACT, bool FROM_DSI, typename OT>
-__global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
+// operands of one step, fetched one step ahead of their use (software prefetch: a scan line is
+// a serial chain, so without it every step would expose a full L2/HBM round trip)
+template <int DPL, bool FROM_DSI>
+struct StepIn {
+    u32 w[FROM_DSI ? DPL / 2 : DPL]; // census words of the right image, or packed u16 costs
+    u32 clv;
+    int I;
+};
+
+template <int DPL, bool EXACT, bool FROM_DSI>
+__device__ __forceinline__ void load_step(StepIn<DPL, FROM_DSI> &s, const u8 *gray_f, const u32 *cl_f, const u32 *cr_f,
+                                          const u16 *dsi_f, int pixl, int D, int dbase, const u32 (&inact)[DPL / 2])
 {
     constexpr int NP = DPL / 2;
+    if constexpr (FROM_DSI) {
+        const u32 *cp = (const u32 *)(dsi_f + (size_t)((u32)pixl * (u32)D + (u32)dbase));
+        if (EXACT) {
+            load_words<NP>(cp, s.w);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; i++) s.w[i] = inact[i] ? 0u : cp[i];
+        }
+        s.clv = 0;
+    } else {
+        load_words<DPL>(cr_f + (pixl - dbase - (DPL - 1)), s.w); // w[j] = cr[x - (dbase + DPL-1-j)]
+        s.clv = cl_f[pixl];
+    }
+    s.I = gray_f[pixl];
+}
+
+// packed matching costs of one step.  d > x has no right-image pixel: InvalidDispCost.
+template <int DPL, bool FROM_DSI>
+__device__ __forceinline__ void step_costs(const StepIn<DPL, FROM_DSI> &s, int lim /* k valid iff k <= lim */,
+                                           u32 (&C)[DPL / 2])
+{
+    constexpr int NP = DPL / 2;
+    if constexpr (FROM_DSI) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) C[i] = s.w[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            u32 c0 = __popc(s.clv ^ s.w[DPL - 1 - 2 * i]);
+            u32 c1 = __popc(s.clv ^ s.w[DPL - 2 - 2 * i]);
+            c0 = (2 * i <= lim) ? c0 : INVALID_DISP_COST;
+            c1 = (2 * i + 1 <= lim) ? c1 : INVALID_DISP_COST;
+            C[i] = (c1 << 16) | c0;
+        }
+    }
+}
+
+template <int DPL, bool EXACT, typename OT>
+__device__ __forceinline__ void store_step(OT *out_f, int pixl, int D, int dbase, const u32 (&L)[DPL / 2],
+                                           const u32 (&inact)[DPL / 2])
+{
+    constexpr int NP = DPL / 2;
+    const u32 off = (u32)pixl * (u32)D + (u32)dbase;
+    if constexpr (sizeof(OT) == 2) {
+        u32 *op = (u32 *)((u16 *)out_f + off);
+        if (EXACT) {
+            store_words<NP>(op, L);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; i++)
+                if (!inact[i]) op[i] = L[i];
+        }
+    } else {
+        // u16 pairs -> bytes (values are < 256 by construction of the u8 variant)
+        u32 bw[NP / 2];
+#pragma unroll
+        for (int i = 0; i + 1 < NP; i += 2) bw[i / 2] = __builtin_amdgcn_perm(L[i + 1], L[i], 0x06040200u);
+        store_words<NP / 2>((u32 *)((u8 *)out_f + off), bw);
+    }
+}
+
+// state of one scan line while it is being walked
+template <int DPL>
+struct LineState {
+    u32 L[DPL / 2];
+    u32 minpk;
+    int prevI;
+};
+
+template <int DPL, bool EXACT, bool FROM_DSI, typename OT, bool DIAG, int GW>
+__device__ __forceinline__ void line_step(LineState<DPL> &st, const StepIn<DPL, FROM_DSI> &in, OT *out_f, const u16 *s_lut,
+                                          int x, int pixl, int D, int dbase, int wrap_edge, u32 P1pk,
+                                          const u32 (&inact)[DPL / 2], bool first, bool last, bool line_active)
+{
+    constexpr int NP = DPL / 2;
+    int di = in.I - st.prevI;
+    di = di < 0 ? -di : di;
+    const u32 P2pk = pk_splat(s_lut[di]);
+    if (DIAG) {
+        // chain restart at the image border (missing predecessor => L = C): with L = 0 and min = 0
+        // the update yields exactly C whatever P2 is
+        const u32 keep = (x == wrap_edge) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < NP; i++) st.L[i] &= keep;
+        st.minpk &= keep;
+    }
+    // byte volumes (no saturation possible) computed from the census pair fuse the cost add into
+    // the popcounts; the masked form is only needed where d can exceed x (first D-1 columns).
+    // Wave-uniform branch: only those waves pay for the selects.
+    constexpr bool CAN_FUSE = !FROM_DSI && EXACT && sizeof(OT) == 1;
+    const int lim = x - dbase;
+    if (CAN_FUSE && __builtin_amdgcn_ballot_w64(lim < DPL - 1) == 0) {
+        u32 X0[NP], X1[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            X0[i] = in.clv ^ in.w[(FROM_DSI ? NP : DPL) - 1 - (FROM_DSI ? 0 : 2 * i)];
+            X1[i] = in.clv ^ in.w[(FROM_DSI ? NP : DPL) - (FROM_DSI ? 1 : 2) - (FROM_DSI ? 0 : 2 * i)];
+        }
+        sgm_update<NP, EXACT, GW, true>(st.L, X0, X0, X1, P1pk, P2pk, st.minpk, inact, first, last);
+    } else {
+        u32 C[NP];
+        step_costs<DPL, FROM_DSI>(in, FROM_DSI ? DPL : lim, C);
+        sgm_update<NP, EXACT, GW, false>(st.L, C, C, C, P1pk, P2pk, st.minpk, inact, first, last);
+    }
+    if (line_active) store_step<DPL, EXACT, OT>(out_f, pixl, D, dbase, st.L, inact);
+    st.prevI = in.I;
+}
+
+// one scan line (GW lanes) from start to end; DIAG lines restart where they wrap around the
+// image.  The loop is unrolled by two with ping-pong operand buffers so that the loads of
+// step t+1 are in flight while step t computes, without register copies.
+template <int DPL, bool EXACT, bool FROM_DSI, typename OT, bool DIAG, int GW>
+__device__ __forceinline__ void run_line(const u8 *gray_f, const u32 *cl_f, const u32 *cr_f, const u16 *dsi_f, OT *out_f,
+                                         const u16 *s_lut, int Wp, int D, int x, int y, int dxs, int dys, int nsteps,
+                                         int dbase, u32 P1pk, bool first, bool last, bool line_active)
+{
+    constexpr int NP = DPL / 2;
+    u32 inact[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) inact[i] = (!EXACT && (dbase + 2 * i >= D)) ? 0xFFFFFFFFu : 0u;
+    const int wrap_edge = dxs > 0 ? 0 : Wp - 1;
+    LineState<DPL> st;
+#pragma unroll
+    for (int i = 0; i < NP; i++) st.L[i] = 0; // first step: L = 0, min = 0 => L = C
+    st.minpk = 0;
+    int pix0 = y * Wp + x, x0 = x;
+    StepIn<DPL, FROM_DSI> A, Bq;
+    load_step<DPL, EXACT, FROM_DSI>(A, gray_f, cl_f, cr_f, dsi_f, pix0, D, dbase, inact);
+    st.prevI = A.I;
+    for (int t = 0; t < nsteps; t += 2) {
+        // position of step t+1 (clamped at the end of the line: a harmless reload)
+        int x1 = x0 + dxs;
+        x1 = x1 >= Wp ? x1 - Wp : (x1 < 0 ? x1 + Wp : x1);
+        y += dys;
+        const bool have1 = t + 1 < nsteps;
+        const int pix1 = have1 ? y * Wp + x1 : pix0;
+        load_step<DPL, EXACT, FROM_DSI>(Bq, gray_f, cl_f, cr_f, dsi_f, pix1, D, dbase, inact);
+        line_step<DPL, EXACT, FROM_DSI, OT, DIAG, GW>(st, A, out_f, s_lut, x0, pix0, D, dbase, wrap_edge, P1pk, inact,
+                                                      first, last, line_active);
+        // position of step t+2
+        int x2 = x1 + dxs;
+        x2 = x2 >= Wp ? x2 - Wp : (x2 < 0 ? x2 + Wp : x2);
+        y += dys;
+        const int pix2 = (t + 2 < nsteps) ? y * Wp + x2 : pix1;
+        load_step<DPL, EXACT, FROM_DSI>(A, gray_f, cl_f, cr_f, dsi_f, pix2, D, dbase, inact);
+        if (have1)
+            line_step<DPL, EXACT, FROM_DSI, OT, DIAG, GW>(st, Bq, out_f, s_lut, x1, pix1, D, dbase, wrap_edge, P1pk, inact,
+                                                          first, last, line_active);
+        x0 = x2;
+        pix0 = pix2;
+    }
+}
+
+template <int GW, int DPL, bool EXACT, bool FROM_DSI, typename OT>
+__global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
+{
+    constexpr int LPB = 256 / GW; // scan lines per block
     __shared__ u16 s_lut[256];
     s_lut[threadIdx.x] = a.p2lut[threadIdx.x];
     __syncthreads();
 
-    const int dir = blockIdx.y;
-    const int f = blockIdx.z;
+    // blockIdx.x enumerates (line block, direction, frame).  When the batch is a multiple of 8
+    // the enumeration is XCD-aware: consecutive block ids go round-robin to the 8 XCDs, so frame
+    // f is pinned to XCD f % 8 and its census / gray rows stay in one 4 MiB L2.
+    const int nlb = a.nlb; // line blocks per direction
+    const int per_frame = nlb * 8;
+    int f, within;
+    if (a.B % 8 == 0) {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        f = (j / per_frame) * 8 + xcd;
+        within = j % per_frame;
+    } else {
+        f = blockIdx.x / per_frame;
+        within = blockIdx.x % per_frame;
+    }
+    // long (horizontal) lines first so that they do not form the tail of the launch
+    const int dslot = within / nlb, lb = within % nlb;
+    const int dir = (dslot == 0) ? 0 : (dslot == 1 ? 4 : (dslot < 5 ? dslot - 1 : dslot));
     const bool horiz = (dir == 0 || dir == 4);
     const int nlines = horiz ? a.Hp : a.Wp;
-    if ((int)blockIdx.x * 16 >= nlines) return;
-    int line = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (lb * LPB >= nlines) return;
+    int line = lb * LPB + (threadIdx.x / GW);
     const bool line_active = line < nlines; // partial last block: redo the last line, store nothing
     line = line_active ? line : nlines - 1;
-    const int l16 = threadIdx.x & 15;
+    const int lg = threadIdx.x % GW;
     const int nsteps = horiz ? a.Wp : a.Hp;
     const int Wp = a.Wp, Hp = a.Hp, D = a.D;
 
@@ -294,121 +518,53 @@ __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
         dxs = (dir == 2 || dir == 6) ? 0 : ((dir == 1 || dir == 7) ? 1 : -1);
     }
     const bool diag = (dxs != 0) && (dys != 0);
-    const int wrap_edge = dxs > 0 ? 0 : Wp - 1;
-
-    const int dbase = DPL * l16;
-    u32 inact[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) inact[i] = (!EXACT && (dbase + 2 * i >= D)) ? 0xFFFFFFFFu : 0u;
-
+    const int dbase = DPL * lg;
     const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
-    OT *outv = (OT *)a.out + (size_t)dir * a.vol_elems;
-
-    u32 L[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) L[i] = 0;
-    u32 minpk = 0;
-    int prevI = 0;
-
-    for (int t = 0; t < nsteps; t++) {
-        const size_t pix = ((size_t)f * Hp + y) * Wp + x;
-        // ---- matching cost for this pixel ------------------------------------------------
-        u32 C[NP];
-        if (FROM_DSI) {
-            const u32 *cp = (const u32 *)(a.dsi + pix * D + dbase);
-            if (EXACT) {
-                load_words<NP>(cp, C);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NP; i++) C[i] = inact[i] ? 0u : cp[i];
-            }
-        } else {
-            u32 w[DPL];
-            load_words<DPL>(a.cr + pix - dbase - (DPL - 1), w); // w[j] = cr[x - (dbase + DPL-1-j)]
-            const u32 clv = a.cl[pix];
-            const int lim = x - dbase; // k valid iff k <= lim
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                u32 c0 = __popc(clv ^ w[DPL - 1 - 2 * i]);
-                u32 c1 = __popc(clv ^ w[DPL - 2 - 2 * i]);
-                C[i] = c0 | (c1 << 16);
-            }
-            // d > x has no right-image pixel: InvalidDispCost.  Wave-uniform branch: only the
-            // waves whose columns sit in the first D-1 pixels of a row pay for the selects.
-            if (__builtin_amdgcn_ballot_w64(lim < DPL - 1) != 0) {
-#pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    const u32 lo = (2 * i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
-                    const u32 hi = (2 * i + 1 <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
-                    C[i] = lo | (hi << 16);
-                }
-            }
-        }
-        const int I = a.gray[pix];
-        // ---- chain restart at the image border (missing predecessor => L = C) -------------
-        const bool reset = (t == 0) || (diag && x == wrap_edge);
-        u32 P2pk;
-        if (reset) {
-#pragma unroll
-            for (int i = 0; i < NP; i++) L[i] = 0;
-            minpk = 0;
-            P2pk = 0;
-        } else {
-            int di = I - prevI;
-            di = di < 0 ? -di : di;
-            P2pk = pk_splat(s_lut[di]);
-        }
-        sgm_update<NP, EXACT>(L, C, P1pk, P2pk, minpk, inact);
-        // ---- store this path's L -----------------------------------------------------------
-        if (!line_active) {
-            // nothing to store
-        } else if (sizeof(OT) == 2) {
-            u32 *op = (u32 *)((u16 *)outv + pix * D + dbase);
-            if (EXACT) {
-                store_words<NP>(op, L);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NP; i++)
-                    if (!inact[i]) op[i] = L[i];
-            }
-        } else {
-            // u16 pairs -> bytes (values are < 256 by construction of the u8 variant)
-            u32 bw[(NP + 1) / 2];
-#pragma unroll
-            for (int i = 0; i + 1 < NP; i += 2) bw[i / 2] = __builtin_amdgcn_perm(L[i + 1], L[i], 0x06040200u);
-            u8 *ob = (u8 *)outv + pix * D + dbase;
-            if (EXACT) {
-                store_words<NP / 2>((u32 *)ob, (const u32(&)[NP / 2])bw);
-            } else {
-#pragma unroll
-                for (int i = 0; i + 1 < NP; i += 2)
-                    if (!inact[i]) *(u32 *)(ob + 2 * i) = bw[i / 2]; // D % 4 == 0 keeps pairs of pairs together
-            }
-        }
-        prevI = I;
-        x += dxs;
-        x = x >= Wp ? x - Wp : (x < 0 ? x + Wp : x);
-        y += dys;
-    }
+    const size_t fpix = (size_t)f * Hp * Wp;
+    const u8 *gray_f = a.gray + fpix;
+    const u32 *cl_f = FROM_DSI ? nullptr : a.cl + fpix;
+    const u32 *cr_f = FROM_DSI ? nullptr : a.cr + fpix;
+    const u16 *dsi_f = FROM_DSI ? a.dsi + fpix * D : nullptr;
+    OT *out_f = (OT *)a.out + (size_t)dir * a.vol_elems + fpix * D;
+    const bool first = lg == 0, last = lg == GW - 1;
+    if (diag)
+        run_line<DPL, EXACT, FROM_DSI, OT, true, GW>(gray_f, cl_f, cr_f, dsi_f, out_f, s_lut, Wp, D, x, y, dxs, dys,
+                                                     nsteps, dbase, P1pk, first, last, line_active);
+    else
+        run_line<DPL, EXACT, FROM_DSI, OT, false, GW>(gray_f, cl_f, cr_f, dsi_f, out_f, s_lut, Wp, D, x, y, dxs, dys,
+                                                      nsteps, dbase, P1pk, first, last, line_active);
 }
 
-template <int DPL, bool EXACT>
-static int launch_paths_t(vppx_ctx *ctx, const PathArgs &a, int B, bool from_dsi, int elem_bytes)
+template <int GW, int DPL>
+static int launch_paths_t(vppx_ctx *ctx, PathArgs a, int B, bool from_dsi, int elem_bytes)
 {
-    const int nl = a.Hp > a.Wp ? a.Hp : a.Wp;
-    dim3 grid((nl + 15) / 16, 8, B);
+    constexpr int LPB = 256 / GW;
+    a.nlb = ((a.Hp > a.Wp ? a.Hp : a.Wp) + LPB - 1) / LPB;
+    dim3 grid((unsigned)(a.nlb * 8 * B), 1, 1);
+    const bool exact = (a.D == GW * DPL);
     if (from_dsi) {
-        sgm_paths_kernel<DPL, EXACT, true, u16><<<grid, 256, 0, ctx->stream>>>(a);
+        if (exact) sgm_paths_kernel<GW, DPL, true, true, u16><<<grid, 256, 0, ctx->stream>>>(a);
+        else sgm_paths_kernel<GW, DPL, false, true, u16><<<grid, 256, 0, ctx->stream>>>(a);
+    } else if (!exact) {
+        sgm_paths_kernel<GW, DPL, false, false, u16><<<grid, 256, 0, ctx->stream>>>(a);
     } else if (elem_bytes == 2) {
-        sgm_paths_kernel<DPL, EXACT, false, u16><<<grid, 256, 0, ctx->stream>>>(a);
+        sgm_paths_kernel<GW, DPL, true, false, u16><<<grid, 256, 0, ctx->stream>>>(a);
     } else {
-        sgm_paths_kernel<DPL, EXACT, false, u8><<<grid, 256, 0, ctx->stream>>>(a);
+        sgm_paths_kernel<GW, DPL, true, false, u8><<<grid, 256, 0, ctx->stream>>>(a);
     }
     VPPX_CHECK_LAUNCH();
     return 0;
 }
 
+// disparities per lane in the 16-lane-per-pixel kernels (sum / WTA)
 static inline int dpl_for(int D) { return D <= 64 ? 4 : (D <= 128 ? 8 : (D <= 192 ? 12 : 16)); }
+
+int rsgm_paths_elem_bytes(int D, int maxp2)
+{
+    // per-path values are bounded by Cmax + P2max (L_r - min L_r <= P2): bytes suffice when that
+    // is < 256 and D fills the lane layout exactly
+    return (24 + maxp2 <= 255 && D % 64 == 0) ? 1 : 2;
+}
 
 int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
                       const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes)
@@ -416,17 +572,27 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
     PathArgs a;
     a.gray = gray; a.cl = cl; a.cr = cr; a.dsi = dsi; a.p2lut = p2lut; a.out = paths;
     a.Hp = Hp; a.Wp = Wp; a.D = D; a.p1 = p1;
+    a.B = B;
+    a.nlb = 0;
     a.vol_elems = (size_t)B * Hp * Wp * D;
-    const int dpl = dpl_for(D);
-    const bool exact = (D == 16 * dpl);
+    if ((size_t)Hp * Wp * D >= ((size_t)1 << 32)) { vppx_set_error("frame volume too large"); return VPPX_E_UNSUPPORTED; }
     const bool from_dsi = dsi != nullptr;
-    if (from_dsi || !exact) elem_bytes = 2; // those variants always write u16 volumes
-    switch (dpl) {
-    case 4: return exact ? launch_paths_t<4, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<4, false>(ctx, a, B, from_dsi, elem_bytes);
-    case 8: return exact ? launch_paths_t<8, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<8, false>(ctx, a, B, from_dsi, elem_bytes);
-    case 12: return exact ? launch_paths_t<12, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<12, false>(ctx, a, B, from_dsi, elem_bytes);
-    default: return exact ? launch_paths_t<16, true>(ctx, a, B, from_dsi, elem_bytes) : launch_paths_t<16, false>(ctx, a, B, from_dsi, elem_bytes);
+    if (from_dsi || D % 64 != 0) elem_bytes = 2; // those variants always write u16 volumes
+    // lanes per pixel x disparities per lane: few lanes per pixel amortise the per-step overhead
+    // (min reduction, P2 lookup, addressing) over more disparities
+    static int gw_override = -1;
+    if (gw_override < 0) {
+        const char *e = getenv("VPPX_GW"); // experiment knob: lanes per pixel for D = 192
+        gw_override = e ? atoi(e) : 0;
     }
+    if (D <= 64) return launch_paths_t<4, 16>(ctx, a, B, from_dsi, elem_bytes);
+    if (D <= 128) return launch_paths_t<4, 32>(ctx, a, B, from_dsi, elem_bytes);
+    if (D <= 192) {
+        if (gw_override == 16) return launch_paths_t<16, 12>(ctx, a, B, from_dsi, elem_bytes);
+        if (gw_override == 4) return launch_paths_t<4, 48>(ctx, a, B, from_dsi, elem_bytes);
+        return launch_paths_t<8, 24>(ctx, a, B, from_dsi, elem_bytes);
+    }
+    return launch_paths_t<8, 32>(ctx, a, B, from_dsi, elem_bytes);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -480,94 +646,119 @@ __device__ __forceinline__ float wta_rows(const u32 (&S)[DPL / 2], int dbase, in
     return disp;
 }
 
+// A block owns 64 consecutive pixels of one row (4 rounds of 16 pixels).  Besides the left
+// disparity it writes the aggregated volume in one or both of two layouts:
+//   S  [y][x][d]  ("xyd", the reference's dsiAgg layout; stage API only)
+//   ST [y][d][x]  (d-major per row): right-view WTA reads ST[y][d][xr+d], which is coalesced
+//                 across consecutive xr; the 64 x 192 tile is transposed through LDS.
 template <int DPL, bool EXACT, typename IT>
 __global__ void __launch_bounds__(256) sum_wta_kernel(const IT *__restrict__ paths, size_t vol_elems, u16 *__restrict__ S,
-                                                      float *__restrict__ disp, int Hp, int Wp, int D, u32 factor_uniq,
-                                                      int do_subpixel)
+                                                      u16 *__restrict__ ST, float *__restrict__ disp, int Hp, int Wp,
+                                                      int D, u32 factor_uniq, int do_subpixel)
 {
     constexpr int NP = DPL / 2;
-    const size_t npix = (size_t)gridDim.z * 0 + (size_t)Hp * Wp; // per frame
-    const size_t pl = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int f = blockIdx.z;
-    if (pl >= npix) return;
-    const size_t pix = (size_t)f * npix + pl;
-    const int x = (int)(pl % Wp);
+    extern __shared__ __attribute__((aligned(16))) u16 tile[]; // [D][66]
+    const int x0 = blockIdx.x * 64, y = blockIdx.y, f = blockIdx.z;
+    const size_t rowpix = ((size_t)f * Hp + y) * Wp;
     const int l16 = threadIdx.x & 15;
     const int dbase = DPL * l16;
-    u32 acc[NP];
+    for (int it = 0; it < 4; it++) {
+        const int p = it * 16 + (threadIdx.x >> 4);
+        const int x = x0 + p;
+        if (x >= Wp) continue; // uniform per 16-lane group
+        const size_t pix = rowpix + x;
+        u32 acc[NP];
 #pragma unroll
-    for (int i = 0; i < NP; i++) acc[i] = 0;
-    const bool lane_active = EXACT || (dbase < D);
+        for (int i = 0; i < NP; i++) acc[i] = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const IT *vp = paths + (size_t)k * vol_elems + pix * D + dbase;
-        if (sizeof(IT) == 2) {
-            u32 w[NP];
+        for (int k = 0; k < 8; k++) {
+            const IT *vp = paths + (size_t)k * vol_elems + pix * D + dbase;
+            if (sizeof(IT) == 2) {
+                u32 w[NP];
+                if (EXACT) {
+                    load_words<NP>((const u32 *)vp, w);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP; i++) w[i] = (dbase + 2 * i < D) ? ((const u32 *)vp)[i] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], w[i]);
+            } else {
+                u32 w[NP / 2];
+                load_words<NP / 2>((const u32 *)vp, w);
+#pragma unroll
+                for (int i = 0; i < NP / 2; i++) {
+                    acc[2 * i] = pk_adds(acc[2 * i], __builtin_amdgcn_perm(w[i], w[i], 0x0c010c00u));
+                    acc[2 * i + 1] = pk_adds(acc[2 * i + 1], __builtin_amdgcn_perm(w[i], w[i], 0x0c030c02u));
+                }
+            }
+        }
+        if (S) {
+            u32 *sp = (u32 *)(S + pix * D + dbase);
             if (EXACT) {
-                load_words<NP>((const u32 *)vp, w);
+                store_words<NP>(sp, acc);
             } else {
 #pragma unroll
-                for (int i = 0; i < NP; i++) w[i] = (dbase + 2 * i < D) ? ((const u32 *)vp)[i] : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], w[i]);
-        } else {
-            u32 w[NP / 2];
-            load_words<NP / 2>((const u32 *)vp, w);
-#pragma unroll
-            for (int i = 0; i < NP / 2; i++) {
-                acc[2 * i] = pk_adds(acc[2 * i], __builtin_amdgcn_perm(w[i], w[i], 0x0c010c00u));
-                acc[2 * i + 1] = pk_adds(acc[2 * i + 1], __builtin_amdgcn_perm(w[i], w[i], 0x0c030c02u));
+                for (int i = 0; i < NP; i++)
+                    if (dbase + 2 * i < D) sp[i] = acc[i];
             }
         }
-    }
-    if (S) {
-        u32 *sp = (u32 *)(S + pix * D + dbase);
-        if (EXACT) {
-            store_words<NP>(sp, acc);
-        } else {
+        if (ST) {
 #pragma unroll
-            for (int i = 0; i < NP; i++)
-                if (dbase + 2 * i < D) sp[i] = acc[i];
+            for (int i = 0; i < NP; i++) {
+                const int d0 = dbase + 2 * i;
+                if (EXACT || d0 < D) {
+                    tile[d0 * 66 + p] = (u16)(acc[i] & 0xFFFFu);
+                    tile[(d0 + 1) * 66 + p] = (u16)(acc[i] >> 16);
+                }
+            }
+        }
+        if (disp) {
+            const int n = (x < D - 1 ? x : D - 1) + 1;
+            const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
+            if (l16 == 0) disp[pix] = dv;
         }
     }
-    (void)lane_active;
-    if (disp) {
-        const int n = (x < D - 1 ? x : D - 1) + 1;
-        const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
-        if (l16 == 0) disp[pix] = dv;
+    if (ST) {
+        __syncthreads();
+        const u32 *t32 = (const u32 *)tile;
+        u32 *o32 = (u32 *)(ST + ((size_t)f * Hp + y) * D * Wp);
+        for (int idx = threadIdx.x; idx < D * 32; idx += 256) {
+            const int d = idx >> 5, j = idx & 31;
+            if (x0 + 2 * j < Wp) o32[((size_t)d * Wp + x0) / 2 + j] = t32[d * 33 + j];
+        }
     }
 }
 
 template <int DPL>
 static int launch_sum_wta_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
-                            float *disp, u32 fu, int sub)
+                            u16 *ST, float *disp, u32 fu, int sub)
 {
-    const size_t npix = (size_t)Hp * Wp;
-    dim3 grid((unsigned)((npix + 15) / 16), 1, B);
-    const size_t vol = (size_t)B * npix * D;
+    dim3 grid((Wp + 63) / 64, Hp, B);
+    const size_t vol = (size_t)B * Hp * Wp * D;
     const bool exact = (D == 16 * DPL);
+    const size_t lds = ST ? (size_t)D * 66 * sizeof(u16) : 0;
     if (elem_bytes == 1) {
-        sum_wta_kernel<DPL, true, u8><<<grid, 256, 0, ctx->stream>>>((const u8 *)paths, vol, S, disp, Hp, Wp, D, fu, sub);
+        sum_wta_kernel<DPL, true, u8><<<grid, 256, lds, ctx->stream>>>((const u8 *)paths, vol, S, ST, disp, Hp, Wp, D, fu, sub);
     } else if (exact) {
-        sum_wta_kernel<DPL, true, u16><<<grid, 256, 0, ctx->stream>>>((const u16 *)paths, vol, S, disp, Hp, Wp, D, fu, sub);
+        sum_wta_kernel<DPL, true, u16><<<grid, 256, lds, ctx->stream>>>((const u16 *)paths, vol, S, ST, disp, Hp, Wp, D, fu, sub);
     } else {
-        sum_wta_kernel<DPL, false, u16><<<grid, 256, 0, ctx->stream>>>((const u16 *)paths, vol, S, disp, Hp, Wp, D, fu, sub);
+        sum_wta_kernel<DPL, false, u16><<<grid, 256, lds, ctx->stream>>>((const u16 *)paths, vol, S, ST, disp, Hp, Wp, D, fu, sub);
     }
     VPPX_CHECK_LAUNCH();
     return 0;
 }
 
 int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
-                        float *disp_l, u32 factor_uniq, int do_subpixel)
+                        u16 *ST, float *disp_l, u32 factor_uniq, int do_subpixel)
 {
     const int dpl = dpl_for(D);
     if (D != 16 * dpl) elem_bytes = 2;
     switch (dpl) {
-    case 4: return launch_sum_wta_t<4>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
-    case 8: return launch_sum_wta_t<8>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
-    case 12: return launch_sum_wta_t<12>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
-    default: return launch_sum_wta_t<16>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, disp_l, factor_uniq, do_subpixel);
+    case 4: return launch_sum_wta_t<4>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, ST, disp_l, factor_uniq, do_subpixel);
+    case 8: return launch_sum_wta_t<8>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, ST, disp_l, factor_uniq, do_subpixel);
+    case 12: return launch_sum_wta_t<12>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, ST, disp_l, factor_uniq, do_subpixel);
+    default: return launch_sum_wta_t<16>(ctx, B, Hp, Wp, D, paths, elem_bytes, S, ST, disp_l, factor_uniq, do_subpixel);
     }
 }
 
@@ -651,7 +842,55 @@ int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 
 }
 
 // ---------------------------------------------------------------------------------------
-// right-view WTA (call site rsgm.py:170): d_R(y,x) = argmin_d S[y, x+d, d].
+// right-view WTA (call site rsgm.py:170): d_R(y,x) = argmin_d S[y, x+d, d], same uniqueness rule.
+// Two readers:
+//   wta_right_t_kernel : from the d-major volume ST[y][d][x] (fused path): one thread per right
+//                        pixel, ST[y][d][xr+d] is coalesced across xr; single pass over d.
+//   wta_right_kernel   : from the reference-layout S[y][x][d] (stage API): diagonal band staged
+//                        through LDS.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wta_right_t_kernel(const u16 *__restrict__ ST, float *__restrict__ disp, int Hp, int Wp,
+                                                          int D, u32 factor_uniq)
+{
+    const int xr = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (xr >= Wp) return;
+    const u16 *row = ST + ((size_t)f * Hp + y) * D * Wp + xr; // element d at row[d*Wp + d]
+    const int n = (Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1;
+    u32 minc = row[0], sec = 65535u, prev = 0, cm1 = 0, cp1 = 0;
+    int best = 0;
+    bool want_next = true; // the candidate after a new best is its d+1 neighbour
+    for (int d = 1; d < n; d++) {
+        const u32 c = row[(size_t)d * Wp + d];
+        if (want_next) { cp1 = c; want_next = false; }
+        if (c < minc) {       // strictly smaller: first minimum wins ties
+            sec = min(sec, minc);
+            cm1 = (d == 1) ? row[0] : prev;
+            minc = c;
+            best = d;
+            want_next = true;
+        } else {
+            sec = min(sec, c);
+        }
+        prev = c;
+    }
+    bool ok = (1024u * minc <= sec * factor_uniq);
+    if (!ok) {
+        if (best > 0 && cm1 == sec) ok = true;
+        if (best + 1 < n && cp1 == sec) ok = true;
+    }
+    disp[((size_t)f * Hp + y) * Wp + xr] = ok ? (float)best : INVALID_DISP;
+}
+
+int rsgm_launch_wta_right_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *ST, float *disp, u32 fu)
+{
+    dim3 grid((Wp + 255) / 256, Hp, B);
+    wta_right_t_kernel<<<grid, 256, 0, ctx->stream>>>(ST, disp, Hp, Wp, D, fu);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// stage-API reader (reference layout):
 // A block owns XR consecutive right pixels of one row.  The diagonal band of S it needs is
 // staged through LDS with coalesced reads: for source pixel xs the needed disparities are
 // d in [xs-x0-XR+1, xs-x0] (contiguous), so every S element is read exactly once overall.

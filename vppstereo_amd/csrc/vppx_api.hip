@@ -315,7 +315,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
     VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
     // per-path values are bounded by Cmax + P2max (L_r - min L_r <= P2): bytes suffice when that is < 256
-    const int elem_bytes = (24 + maxp2 <= 255 && g.D % 64 == 0) ? 1 : 2;
+    const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
     void *paths;
     if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * elem_bytes, &paths))) return rc;
     u16 *S;
@@ -331,9 +331,9 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_DISP_R1, npp, &dr1))) return rc;
     const u32 fu = uniq_factor(p.uniqueness);
     // rsgm.py:141-142: matchWTA_SSE + subPixelRefine(.., 0) are always applied to the left map
-    if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, S, dl0, fu, 1))) return rc;
+    if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, nullptr, S, dl0, fu, 1))) return rc;
     stage_mark(ctx, ST_SUM_WTA);
-    if ((rc = rsgm_launch_wta_right(ctx, g.B, g.Hp, g.Wp, g.D, S, dr0, fu))) return rc;
+    if ((rc = rsgm_launch_wta_right_t(ctx, g.B, g.Hp, g.Wp, g.D, S, dr0, fu))) return rc;
     stage_mark(ctx, ST_WTA_RIGHT);
     if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dl0, dl1))) return rc;
     if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dr0, dr1))) return rc;
@@ -666,7 +666,7 @@ extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t 
     if ((rc = ws_reserve(ctx, WS_PATHS, nc * 8 * 2, &paths))) return rc;
     if ((rc = ws_get(ctx, WS_S, nc, &S))) return rc;
     if ((rc = rsgm_launch_paths(ctx, 1, h, w, dmax, (const u8 *)dimg, nullptr, nullptr, (const u16 *)ddsi, lut_d, p1, paths, 2))) return rc;
-    if ((rc = rsgm_launch_sum_wta(ctx, 1, h, w, dmax, paths, 2, S, nullptr, 0, 0))) return rc;
+    if ((rc = rsgm_launch_sum_wta(ctx, 1, h, w, dmax, paths, 2, S, nullptr, nullptr, 0, 0))) return rc;
     if ((rc = download(ctx, dsi_agg, S, nc * sizeof(u16)))) return rc;
     VPPX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -742,7 +742,7 @@ extern "C" int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out)
     u16 lut_h[256];
     int maxp2;
     p2_lut_host(p, lut_h, &maxp2);
-    const int elem_bytes = (24 + maxp2 <= 255 && ctx->last_D % 64 == 0) ? 1 : 2;
+    const int elem_bytes = rsgm_paths_elem_bytes(ctx->last_D, maxp2);
     hipEvent_t e0, e1;
     VPPX_HIP(hipEventCreate(&e0));
     VPPX_HIP(hipEventCreate(&e1));

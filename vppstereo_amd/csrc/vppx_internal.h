@@ -154,7 +154,9 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
                       const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes);
 // S = sum of the 8 path volumes (+ left WTA, sub-pixel) ; disp_l may be null (stage API: S only)
 int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
-                        float *disp_l, u32 factor_uniq, int do_subpixel);
+                        u16 *ST, float *disp_l, u32 factor_uniq, int do_subpixel);
+int rsgm_launch_wta_right_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *ST, float *disp, u32 factor_uniq);
+int rsgm_paths_elem_bytes(int D, int maxp2);
 int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
 int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp);
 int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
