@@ -763,6 +763,119 @@ int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void 
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused sum + left WTA + right WTA (fast path, D = 64/128/192): one block walks one image row
+// in rounds of 64 pixels and keeps the last D/64+1 aggregated 64 x D tiles in an LDS ring, so
+// the right view (d_R(x) = argmin_d S[x+d][d], needs x .. x+D-1) is read from LDS instead of a
+// second pass over HBM: the path volumes are read once and S is never written.
+// ---------------------------------------------------------------------------------------
+template <int DPL, typename IT>
+__global__ void __launch_bounds__(1024) sum_wta_lr_kernel(const IT *__restrict__ paths, size_t vol_elems,
+                                                          float *__restrict__ disp_l, float *__restrict__ disp_r, int Hp,
+                                                          int Wp, u32 factor_uniq, int do_subpixel)
+{
+    constexpr int NP = DPL / 2;
+    constexpr int D = 16 * DPL;
+    constexpr int NR = D / 64 + 1;   // tiles a right pixel can touch
+    constexpr int NT = NR + 1;       // ring slots: one spare so that a single barrier per round suffices
+    constexpr int TS = D * 66;       // u16 per tile ([D][66], 2 pad)
+    constexpr int NWD = (sizeof(IT) == 2) ? NP : NP / 2; // dwords per lane per volume
+    extern __shared__ __attribute__((aligned(16))) u16 ring[]; // [NT][D][66]
+    const int y = blockIdx.x, f = blockIdx.y;
+    const size_t rowpix = ((size_t)f * Hp + y) * Wp;
+    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int dbase = DPL * l16;
+    const int ntiles = (Wp + 63) / 64;
+    u32 w[8][NWD]; // operands of the next round, fetched one round ahead
+    auto fetch = [&](int k) {
+        int x = 64 * k + g;
+        x = x < Wp ? x : Wp - 1;
+        const size_t pix = rowpix + x;
+#pragma unroll
+        for (int v = 0; v < 8; v++) load_words<NWD>((const u32 *)(paths + (size_t)v * vol_elems + pix * D + dbase), w[v]);
+    };
+    fetch(0);
+    for (int k = 0; k < ntiles + NR - 1; k++) {
+        if (k < ntiles) {
+            const int x = 64 * k + g;
+            u32 acc[NP];
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc[i] = 0;
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                if (sizeof(IT) == 2) {
+#pragma unroll
+                    for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], w[v][i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP / 2; i++) {
+                        acc[2 * i] = pk_adds(acc[2 * i], __builtin_amdgcn_perm(w[v][i], w[v][i], 0x0c010c00u));
+                        acc[2 * i + 1] = pk_adds(acc[2 * i + 1], __builtin_amdgcn_perm(w[v][i], w[v][i], 0x0c030c02u));
+                    }
+                }
+            }
+            if (k + 1 < ntiles) fetch(k + 1); // in flight across the barrier and the right-view phase
+            if (x < Wp) { // uniform per 16-lane group
+                u16 *t = ring + (k % NT) * TS + g;
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    t[(dbase + 2 * i) * 66] = (u16)(acc[i] & 0xFFFFu);
+                    t[(dbase + 2 * i + 1) * 66] = (u16)(acc[i] >> 16);
+                }
+                const int n = (x < D - 1 ? x : D - 1) + 1;
+                const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
+                if (l16 == 0) disp_l[rowpix + x] = dv;
+            }
+        }
+        __syncthreads();
+        const int kr = k - (NR - 1);
+        if (kr >= 0) {
+            const int xr = 64 * kr + g;
+            if (xr < Wp) {
+                const int n = (Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1;
+                u32 sr[NP];
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const int d0 = dbase + 2 * i, d1 = d0 + 1;
+                    const int xa = xr + d0, xb = xr + d1;
+                    const u32 lo = ring[((xa >> 6) % NT) * TS + d0 * 66 + (xa & 63)];
+                    const u32 hi = ring[((xb >> 6) % NT) * TS + d1 * 66 + (xb & 63)];
+                    sr[i] = lo | (hi << 16);
+                }
+                const float dv = wta_rows<DPL>(sr, dbase, n, D, factor_uniq, false, false);
+                if (l16 == 0) disp_r[rowpix + xr] = dv;
+            }
+        }
+    }
+}
+
+int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, float *disp_l,
+                           float *disp_r, u32 fu, int sub)
+{
+    if (D != 64 && D != 128 && D != 192) return 1; // caller falls back to the two-kernel form
+    dim3 grid(Hp, B);
+    const size_t vol = (size_t)B * Hp * Wp * D;
+    const size_t lds = (size_t)(D / 64 + 2) * D * 66 * sizeof(u16);
+#define LAUNCH_LR(DPLV, T)                                                                                          \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPLV, T>,                                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        sum_wta_lr_kernel<DPLV, T><<<grid, 1024, lds, ctx->stream>>>((const T *)paths, vol, disp_l, disp_r, Hp, Wp, fu, sub); \
+    } while (0)
+    if (elem_bytes == 1) {
+        if (D == 64) LAUNCH_LR(4, u8); else if (D == 128) LAUNCH_LR(8, u8); else LAUNCH_LR(12, u8);
+    } else {
+        if (D == 64) LAUNCH_LR(4, u16); else if (D == 128) LAUNCH_LR(8, u16); else LAUNCH_LR(12, u16);
+    }
+#undef LAUNCH_LR
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // stand-alone left WTA / sub-pixel on a materialised S (stage API: rsgm.py:141-142)
 // ---------------------------------------------------------------------------------------
 template <int DPL, bool SUBPIX_ONLY>

@@ -318,8 +318,6 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
     void *paths;
     if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * elem_bytes, &paths))) return rc;
-    u16 *S;
-    if ((rc = ws_get(ctx, WS_S, ncell, &S))) return rc;
     if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes))) return rc;
     stage_mark(ctx, ST_AGGREGATE);
     ctx->last_B = g.B; ctx->last_Hp = g.Hp; ctx->last_Wp = g.Wp; ctx->last_D = g.D; ctx->last_rp = p; ctx->have_last = true;
@@ -331,10 +329,18 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_DISP_R1, npp, &dr1))) return rc;
     const u32 fu = uniq_factor(p.uniqueness);
     // rsgm.py:141-142: matchWTA_SSE + subPixelRefine(.., 0) are always applied to the left map
-    if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, nullptr, S, dl0, fu, 1))) return rc;
-    stage_mark(ctx, ST_SUM_WTA);
-    if ((rc = rsgm_launch_wta_right_t(ctx, g.B, g.Hp, g.Wp, g.D, S, dr0, fu))) return rc;
-    stage_mark(ctx, ST_WTA_RIGHT);
+    rc = rsgm_launch_sum_wta_lr(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, dl0, dr0, fu, 1);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+        stage_mark(ctx, ST_SUM_WTA);
+    } else {
+        u16 *S;
+        if ((rc = ws_get(ctx, WS_S, ncell, &S))) return rc;
+        if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, nullptr, S, dl0, fu, 1))) return rc;
+        stage_mark(ctx, ST_SUM_WTA);
+        if ((rc = rsgm_launch_wta_right_t(ctx, g.B, g.Hp, g.Wp, g.D, S, dr0, fu))) return rc;
+        stage_mark(ctx, ST_WTA_RIGHT);
+    }
     if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dl0, dl1))) return rc;
     if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dr0, dr1))) return rc;
     if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dl1, dl0))) return rc;
