@@ -68,6 +68,64 @@ def test_rnd_golden_cases_bit_exact(gpu):
     assert not bad, bad[:8]
 
 
+def test_maxdist_golden_cases_bit_exact(gpu):
+    """virtual_projection_scan_max_dist (vpp_core_opt.pyx:133-341) incl. the n_bins==0 fallback."""
+    store = np.load(os.path.join(GOLDEN, "vpp_cases.npz"))
+    with open(os.path.join(GOLDEN, "vpp_cases.json")) as f:
+        cases = [c for c in json.load(f) if c["method"] == "maxdist"]
+    assert len(cases) > 40 and any(c["inp"] == "fallback" for c in cases)
+    bad = []
+    for case in cases:
+        n, l, r = run_case(gpu, case, store)
+        ok = n == case["n_hints"] and np.array_equal(l, store[case["name"] + "_l"]) and \
+            np.array_equal(r, store[case["name"] + "_r"])
+        if not ok:
+            bad.append((case["name"], {k: case[k] for k in ("inp", "uniform", "direction", "interpolate", "discard",
+                                                           "c_occ", "wsize", "use_occ", "agg_x", "agg_y")},
+                        int((l != store[case["name"] + "_l"]).sum()), int((r != store[case["name"] + "_r"]).sum())))
+    assert not bad, bad[:8]
+
+
+def test_maxdist_vs_oracle_random_inputs(gpu):
+    rng = np.random.default_rng(77)
+    for (H, W, C, p, dmax) in [(30, 90, 3, 0.05, 20.0), (24, 200, 1, 0.03, 120.0), (9, 11, 3, 0.4, 5.0)]:
+        for trial in range(4):
+            l = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+            r = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+            if trial == 3:  # low-contrast images: many ties and narrow intervals
+                l = (l // 64 * 64).astype(np.uint8)
+                r = (r // 64 * 64).astype(np.uint8)
+            g = np.where(rng.random((H, W)) < p, rng.uniform(0.05, dmax, (H, W)), 0).astype(np.float32)
+            g[rng.random((H, W)) < p / 4] = np.float32(rng.integers(1, 9))
+            occ = (rng.random((H, W)) < 0.3).astype(np.uint8)
+            uniform, direction, interp, discard = [bool(b) for b in rng.integers(0, 2, 4)]
+            wsize = int(rng.choice([1, 3, 5]))
+            ax, ay = int(rng.choice([64, 9, 130, 1])), int(rng.choice([3, 1, 5]))
+            c, c_occ = float(np.float32(rng.uniform(0.05, 0.95))), float(np.float32(rng.choice([0.0, 0.3])))
+            a0, b0, a1, b1 = l.copy(), r.copy(), l.copy(), r.copy()
+            n0 = oracle.virtual_projection_scan_max_dist(a0, b0, g, W, H, C, uniform, wsize, ax, ay, direction, c, c_occ,
+                                                         occ, discard, interp)
+            n1 = gpu.virtual_projection_scan_max_dist(a1, b1, g, W, H, C, uniform, wsize, ax, ay, direction, c, c_occ, occ,
+                                                      discard, interp)
+            cfg = dict(uniform=uniform, direction=direction, interp=interp, discard=discard, wsize=wsize, ax=ax, ay=ay)
+            assert n0 == n1, cfg
+            assert np.array_equal(a0, a1), (cfg, int((a0 != a1).sum()))
+            assert np.array_equal(b0, b1), (cfg, int((b0 != b1).sum()))
+
+
+def test_maxdist_full_size_anchor_hash(gpu):
+    with open(os.path.join(GOLDEN, "vpp_anchors.json")) as f:
+        meta = json.load(f)
+    l, r, g, occ0, occ1 = _anchor_inputs(meta)
+    if _sha(l) != meta["inputs"]["l"] or _sha(g) != meta["inputs"]["g"]:
+        pytest.skip("numpy Generator stream differs from the one the anchors were made with")
+    H, W = meta["H"], meta["W"]
+    c = {c["name"]: c for c in meta["cases"]}["maxdist_occ1"]
+    a, b = l.copy(), r.copy()
+    n = gpu.virtual_projection_scan_max_dist(a, b, g, W, H, 3, False, 3, 64, 3, 1, 0.4, 0.0, occ1, False, True)
+    assert n == c["n_hints"] and _sha(a) == c["l"] and _sha(b) == c["r"]
+
+
 def test_rnd_full_size_anchor_hashes(gpu):
     """540x960x3, 3 % hints: SHA-256 of the reference's outputs."""
     with open(os.path.join(GOLDEN, "vpp_anchors.json")) as f:

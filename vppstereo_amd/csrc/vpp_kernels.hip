@@ -47,6 +47,7 @@ struct VppK {
     const u8 *occ;       // may be null
     const float *filled; // may be null
     HintRec *rec;        // [B][H][W]
+    u32 *rng;            // [B][H][W] per hint: R-target column range lo | hi<<16 (int16 each)
     uint2 *dense;        // [B][H][W] {idx in row, base in row}
     int *row_count;      // [B][H]
     u32 *row_draws;      // [B][H]
@@ -160,6 +161,12 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
             r.flags = occ | ((u32)(nk & 0xFF) << 8) | ((cnt & 0xFFFFu) << 16);
             k.rec[rowoff + my_idx] = r;
             k.dense[rowoff + x] = make_uint2(my_idx, my_base);
+            // columns of R this hint can touch: [xd0-1-n_k, xd0+n_k] (a negative lo also means the
+            // Python-style wraparound write/read of column W-1, SURVEY C-1/C-2)
+            int lo = x - (int)floorf(gv) - 1 - nk, hi = x - (int)floorf(gv) + nk;
+            lo = lo < -32768 ? -32768 : lo;
+            hi = hi < -32768 ? -32768 : (hi > 32767 ? 32767 : hi);
+            k.rng[rowoff + my_idx] = ((u32)lo & 0xFFFFu) | ((u32)hi << 16);
         }
         __syncthreads();
         if (threadIdx.x == 255) {
@@ -468,8 +475,61 @@ __device__ __forceinline__ u8 draw(const VppK &k, const u8 *rnd, const HintGeo &
     return k.uniform ? rnd[h.base + (u32)j] : rnd[h.base + (u32)j * (u32)h.cnt + (u32)idx];
 }
 
+// All ops of hint i of row yy (scan order) that touch R pixel (yp, q), for every channel, with
+// xw <= xw_lim.  R[] carries the pixel through the chain.
+__device__ __forceinline__ void r_apply_hint(const VppK &k, int f, int yp, int yy, int i, int q, u8 (&R)[4], const u8 *rnd,
+                                             int xw_lim)
+{
+    const int W = k.W;
+    const size_t rowoff = ((size_t)f * k.H + yy) * W;
+    const HintRec rec = k.rec[rowoff + i];
+    HintGeo h;
+    decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
+    const int yw = yp - yy;
+    if (yw < -h.nk || yw > h.nk) return;
+    if (h.occ && k.discard) return;
+    const float cc = h.occ ? k.c_occ : k.c;
+    const int xd0 = h.x - h.d0, xd1 = h.x - h.d1, xd = h.x - h.d;
+    const int xw_hi = min(h.nk, xw_lim);
+    for (int xw = -h.nk; xw <= xw_hi; xw++) {
+        const int xx = h.x + xw;
+        if (xx < 0 || xx > W - 1) continue;                 // pyx:99
+        if (k.use_bil && !gate_pass(k, f, h.g, yp, xx)) continue;
+        if (!(0 <= xd0 + xw && xd0 + xw <= W - 1)) continue; // pyx:104 (else-branch touches L only)
+        bool hit0, hit1 = false;
+        if (k.interp) {
+            hit0 = (xd0 + xw == q);
+            hit1 = (xd1 + xw >= 0) && (xd1 + xw == q);       // pyx:110,117
+        } else {
+            const int tq = xd + xw;
+            hit0 = ((tq < 0 ? tq + W : tq) == q);            // pyx:113,121 (wraparound)
+        }
+        if (!hit0 && !hit1) continue;
+        const int idx = k.uniform ? 0 : hint_idx(k, f, yy, h.x, h.g, h.nk, yw, xw);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j >= k.C) break;
+            const u8 rv = draw(k, rnd, h, j, idx);
+            if (k.interp) {
+                if (hit0) R[j] = blend_r0(rv, cc, R[j], h.beta);
+                if (hit1) R[j] = blend_r1(rv, cc, R[j], h.beta);
+            } else {
+                R[j] = blend1(rv, cc, R[j]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool rng_hit(u32 rg, int q, int W)
+{
+    // targets lie in [lo, hi] (or wrap -1 -> W-1)
+    const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
+    return (q >= lo && q <= hi) || (q == W - 1 && lo < 0);
+}
+
 // Replay the chain of R pixel (yp, q) for all channels up to and including the op with key
-// (lim_y, lim_i, lim_xw, slot<=lim_slot).  R[] enters with the original pixel.
+// (lim_y, lim_i, lim_xw).  R[] enters with the original pixel.  (Used by the L kernel for the
+// occluded-hint branch, which needs R "as of that instant".)
 __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim_y, int lim_i, int lim_xw)
 {
     const int W = k.W, H = k.H;
@@ -480,65 +540,47 @@ __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim
         int cntrow = k.row_count[(size_t)f * H + yy];
         if (yy == lim_y && lim_i + 1 < cntrow) cntrow = lim_i + 1;
         const u8 *rnd = rnd_f + k.row_base[(size_t)f * H + yy];
-        const int yw = yp - yy;
         for (int i = 0; i < cntrow; i++) {
-            const HintRec rec = k.rec[rowoff + i];
-            const int xd0r = rec.x - (int)floorf(rec.g);
-            const int nkq = (int)(signed char)((rec.flags >> 8) & 0xFFu);
-            // targets lie in [xd0-1-nk, xd0+nk] (or wrap -1 -> W-1)
-            if ((q < xd0r - 1 - nkq || q > xd0r + nkq) && !(q == W - 1 && xd0r - 1 - nkq < 0)) continue;
-            HintGeo h;
-            decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
-            if (yw < -h.nk || yw > h.nk) continue;
-            if (h.occ && k.discard) continue;
-            const float cc = h.occ ? k.c_occ : k.c;
-            const int xd0 = h.x - h.d0, xd1 = h.x - h.d1, xd = h.x - h.d;
+            if (!rng_hit(k.rng[rowoff + i], q, W)) continue;
             const bool at_limit = (yy == lim_y && i == lim_i);
-            const int xw_hi = at_limit ? min(h.nk, lim_xw) : h.nk;
-            for (int xw = -h.nk; xw <= xw_hi; xw++) {
-                const int xx = h.x + xw;
-                if (xx < 0 || xx > W - 1) continue;                 // pyx:99
-                if (k.use_bil && !gate_pass(k, f, h.g, yy + yw, xx)) continue;
-                if (!(0 <= xd0 + xw && xd0 + xw <= W - 1)) continue; // pyx:104 (else-branch touches L only)
-                bool hit0, hit1 = false;
-                if (k.interp) {
-                    hit0 = (xd0 + xw == q);
-                    hit1 = (xd1 + xw >= 0) && (xd1 + xw == q);       // pyx:110,117
-                } else {
-                    const int tq = xd + xw;
-                    hit0 = ((tq < 0 ? tq + W : tq) == q);            // pyx:113,121 (wraparound)
-                }
-                if (!hit0 && !hit1) continue;
-                const int idx = k.uniform ? 0 : hint_idx(k, f, yy, h.x, h.g, h.nk, yw, xw);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (j >= k.C) break;
-                    const u8 rv = draw(k, rnd, h, j, idx);
-                    if (k.interp) {
-                        if (hit0) R[j] = blend_r0(rv, cc, R[j], h.beta);
-                        if (hit1) R[j] = blend_r1(rv, cc, R[j], h.beta);
-                    } else {
-                        R[j] = blend1(rv, cc, R[j]);
-                    }
-                }
-            }
+            r_apply_hint(k, f, yp, yy, i, q, R, rnd, at_limit ? lim_xw : 0x7FFFFFFF);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// 5. R pixels
+// 5. R pixels: a block owns 256 consecutive columns of one row; the compact range list of each
+// contributing hint row is staged through LDS (coalesced) and scanned from there.
 // ---------------------------------------------------------------------------------------
+#define RCH 1024
 __global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
 {
+    __shared__ u32 s_rng[RCH];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int yp = blockIdx.y, f = blockIdx.z;
-    if (q >= k.W) return;
-    u8 *px = k.r + (((size_t)f * k.H + yp) * k.W + q) * k.C;
+    const int W = k.W, H = k.H;
+    const bool live = q < W;
+    u8 *px = k.r + (((size_t)f * H + yp) * W + (live ? q : 0)) * k.C;
     u8 R[4] = {0, 0, 0, 0};
-    for (int j = 0; j < k.C; j++) R[j] = px[j];
-    r_chain(k, f, yp, q, R, k.H, 0x7FFFFFFF, 0x7FFFFFFF);
-    for (int j = 0; j < k.C; j++) px[j] = R[j];
+    if (live)
+        for (int j = 0; j < k.C; j++) R[j] = px[j];
+    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+    for (int yy = max(0, yp - k.n); yy <= min(H - 1, yp + k.n); yy++) {
+        const size_t rowoff = ((size_t)f * H + yy) * W;
+        const int cntrow = k.row_count[(size_t)f * H + yy];
+        const u8 *rnd = rnd_f + k.row_base[(size_t)f * H + yy];
+        for (int c0 = 0; c0 < cntrow; c0 += RCH) {
+            const int nc = min(RCH, cntrow - c0);
+            __syncthreads();
+            for (int t = threadIdx.x; t < nc; t += 256) s_rng[t] = k.rng[rowoff + c0 + t];
+            __syncthreads();
+            if (live)
+                for (int t = 0; t < nc; t++)
+                    if (rng_hit(s_rng[t], q, W)) r_apply_hint(k, f, yp, yy, c0 + t, q, R, rnd, 0x7FFFFFFF);
+        }
+    }
+    if (live)
+        for (int j = 0; j < k.C; j++) px[j] = R[j];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -615,6 +657,206 @@ __global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
 }
 
 // ---------------------------------------------------------------------------------------
+// maxDistance colour method (vpp_core_opt.pyx:133-341).  The colour of every patch pixel is
+// found by a greedy, order-dependent walk over a (wsize_agg_y x wsize_agg_x) window of the
+// CURRENT left and right images, so hints are truly serial (SURVEY C-12); only channels and
+// frames are independent.  One wave owns one (frame, channel) chain and walks the hints in
+// scan order; inside a colour search the 64 lanes hold 64 window columns and the sequential
+// walk jumps from one interval-shrinking sample to the next with ballot + ffs, which visits
+// exactly the samples the reference's loop acts on, in the same order.
+// All image accesses of a chain go through L2-coherent (agent-scope relaxed atomic) byte
+// loads/stores: the chain reads bytes it wrote itself a few instructions earlier.
+// ---------------------------------------------------------------------------------------
+struct MdK {
+    VppK k;
+    int n_agg_x, n_agg_y;
+};
+
+__device__ __forceinline__ u32 md_ld(const u8 *p) { return (u32)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void md_st(u8 *p, u8 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// (u8)( V*cc + P*(1.0-cc) )                                   pyx:318,324,332,335 (V double)
+__device__ __forceinline__ u8 mdblend1(double V, float cc, u8 P)
+{
+    const double a = __dmul_rn(V, (double)cc);
+    const double b = __dmul_rn((double)P, __dsub_rn(1.0, (double)cc));
+    return to_u8(__dadd_rn(a, b));
+}
+// (u8)( (V*cc + R*(1.0-cc)) * (1.0-beta) + R*beta )            pyx:320,327
+__device__ __forceinline__ u8 mdblend_r0(double V, float cc, u8 R, float beta)
+{
+    const double a = __dmul_rn(V, (double)cc);
+    const double b = __dmul_rn((double)R, __dsub_rn(1.0, (double)cc));
+    const double t = __dmul_rn(__dadd_rn(a, b), __dsub_rn(1.0, (double)beta));
+    const double u = (double)__fmul_rn((float)R, beta);
+    return to_u8(__dadd_rn(t, u));
+}
+// (u8)( (V*cc + R*(1.0-cc)) * beta + R*(1.0-beta) )            pyx:322,329
+__device__ __forceinline__ u8 mdblend_r1(double V, float cc, u8 R, float beta)
+{
+    const double a = __dmul_rn(V, (double)cc);
+    const double b = __dmul_rn((double)R, __dsub_rn(1.0, (double)cc));
+    const double t = __dmul_rn(__dadd_rn(a, b), (double)beta);
+    const double u = __dmul_rn((double)R, __dsub_rn(1.0, (double)beta));
+    return to_u8(__dadd_rn(t, u));
+}
+
+// colour search: pyx:216-260 (uniform, bins_inside) / :269-313 (per patch pixel)
+__device__ void md_search(const MdK &m, const u8 *lch, const u8 *rch, int cy, int cx, int rcx, bool occluded,
+                          bool bins_inside, u32 *hist /* LDS [256] */, int &pa_out, int &pb_out)
+{
+    const int W = m.k.W, H = m.k.H, C = m.k.C;
+    const int lane = threadIdx.x & 63;
+    int pa = 0, pb = 255;
+    int zeros = 0;
+    const int ncol = 2 * m.n_agg_x + 1;
+    for (int yw = -m.n_agg_y; yw <= m.n_agg_y; yw++) {
+        const int yy = cy + yw;
+        if (yy < 0 || yy > H - 1) continue;
+        for (int c0 = 0; c0 < ncol; c0 += 64) {
+            const int i = c0 + lane;
+            const int xx = cx - m.n_agg_x + i, rx = rcx - m.n_agg_x + i;
+            const bool inL = (i < ncol) && xx >= 0 && xx <= W - 1;
+            const bool rin = rx >= 0 && rx <= W - 1;
+            const bool condL = inL && (!occluded || !rin);
+            const bool condR = inL && rin;
+            const int Lv = condL ? (int)md_ld(lch + ((size_t)yy * W + xx) * C) : 0;
+            const int Rv = condR ? (int)md_ld(rch + ((size_t)yy * W + rx) * C) : 0;
+            if (!bins_inside) {
+                zeros += __popcll(__ballot(condL && Lv == 0)) + __popcll(__ballot(condR && Rv == 0));
+            }
+            int pos = 0; // next sequence position (2*lane = left sample, 2*lane+1 = right sample)
+            while (true) {
+                const bool candL = condL && Lv > pa && Lv < pb && (2 * lane >= pos);
+                const bool candR = condR && Rv > pa && Rv < pb && (2 * lane + 1 >= pos);
+                const unsigned long long mk = __ballot(candL || candR);
+                if (mk == 0) break;
+                const int fl = __ffsll((long long)mk) - 1;
+                const int isL = __shfl((int)candL, fl);
+                const int p = __shfl(isL ? Lv : Rv, fl);
+                if (p - pa > pb - p) pb = p;
+                else if (p - pa < pb - p) pa = p;
+                pos = 2 * fl + (isL ? 1 : 2);
+            }
+        }
+    }
+    if (!bins_inside && zeros == 256) {
+        // n_bins == 0 (exactly 256 zero-valued samples): least-used bin, first minimum (pyx:305-313)
+        for (int b = lane; b < 256; b += 64) hist[b] = 0;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int yw = -m.n_agg_y; yw <= m.n_agg_y; yw++) {
+            const int yy = cy + yw;
+            if (yy < 0 || yy > H - 1) continue;
+            for (int c0 = 0; c0 < ncol; c0 += 64) {
+                const int i = c0 + lane;
+                const int xx = cx - m.n_agg_x + i, rx = rcx - m.n_agg_x + i;
+                const bool inL = (i < ncol) && xx >= 0 && xx <= W - 1;
+                const bool rin = rx >= 0 && rx <= W - 1;
+                if (inL && (!occluded || !rin)) atomicAdd(&hist[md_ld(lch + ((size_t)yy * W + xx) * C)], 1u);
+                if (inL && rin) atomicAdd(&hist[md_ld(rch + ((size_t)yy * W + rx) * C)], 1u);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        u32 key = 0xFFFFFFFFu; // count*256 + bin: first minimum wins
+        for (int b = lane; b < 256; b += 64) key = min(key, (hist[b] << 8) | (u32)b);
+        for (int off = 32; off >= 1; off >>= 1) key = min(key, (u32)__shfl_xor((int)key, off));
+        pa = pb = (int)(key & 0xFFu);
+    }
+    pa_out = pa;
+    pb_out = pb;
+}
+
+__global__ void __launch_bounds__(64) maxdist_kernel(MdK m)
+{
+    __shared__ u32 hist[256];
+    const VppK &k = m.k;
+    const int f = blockIdx.x / k.C, j = blockIdx.x % k.C;
+    const int W = k.W, H = k.H, C = k.C;
+    const int lane = threadIdx.x & 63;
+    u8 *lch = k.l + (size_t)f * H * W * C + j;
+    u8 *rch = k.r + (size_t)f * H * W * C + j;
+    int pa = 0, pb = 255; // pyx:196-197
+    for (int y = 0; y < H; y++) {
+        const size_t rowoff = ((size_t)f * H + y) * W;
+        const int cnt = k.row_count[(size_t)f * H + y];
+        for (int i = 0; i < cnt; i++) {
+            const HintRec rec = k.rec[rowoff + i];
+            HintGeo h;
+            decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
+            const int x = h.x;
+            const bool occ = h.occ != 0;
+            const int xd0 = x - h.d0, xd1 = x - h.d1, xd = x - h.d;
+            if (k.uniform) md_search(m, lch, rch, y, x, xd, occ, true, hist, pa, pb); // pyx:216-260
+            for (int yw = -h.nk; yw <= h.nk; yw++)
+                for (int xw = -h.nk; xw <= h.nk; xw++) {
+                    const int py = y + yw, pxx = x + xw;
+                    if (py < 0 || py > H - 1 || pxx < 0 || pxx > W - 1) continue;      // pyx:267
+                    if (k.use_bil && !gate_pass(k, f, h.g, py, pxx)) continue;        // vpp_standalone.py:154
+                    if (!k.uniform) md_search(m, lch, rch, py, pxx, xd + xw, occ, false, hist, pa, pb); // pyx:269-313
+                    const double V = __ddiv_rn((double)(pa + pb), 2.0);
+                    u8 *lp = lch + ((size_t)py * W + pxx) * C;
+                    if (0 <= xd0 + xw && xd0 + xw <= W - 1) {                          // pyx:315
+                        if (!occ) {                                                    // pyx:317-324
+                            const u8 Lo = (u8)md_ld(lp);
+                            const u8 Ln = mdblend1(V, k.c, Lo);
+                            if (k.interp) {
+                                u8 *r0 = rch + ((size_t)py * W + xd0 + xw) * C;
+                                const u8 R0n = mdblend_r0(V, k.c, (u8)md_ld(r0), h.beta);
+                                if (lane == 0) { md_st(lp, Ln); md_st(r0, R0n); }
+                                if (0 <= xd1 + xw && xd1 + xw <= W - 1) {
+                                    u8 *r1 = rch + ((size_t)py * W + xd1 + xw) * C;
+                                    __builtin_amdgcn_s_waitcnt(0);
+                                    const u8 R1n = mdblend_r1(V, k.c, (u8)md_ld(r1), h.beta);
+                                    if (lane == 0) md_st(r1, R1n);
+                                }
+                            } else {
+                                int q = xd + xw;
+                                q = q < 0 ? q + W : q;
+                                u8 *rd = rch + ((size_t)py * W + q) * C;
+                                const u8 Rn = mdblend1(V, k.c, (u8)md_ld(rd));
+                                if (lane == 0) { md_st(lp, Ln); md_st(rd, Rn); }
+                            }
+                        } else if (!k.discard) {                                       // pyx:325-333
+                            if (k.interp) {
+                                u8 *r0 = rch + ((size_t)py * W + xd0 + xw) * C;
+                                int q1 = xd1 + xw;
+                                const bool in1 = q1 >= 0 && q1 <= W - 1;
+                                q1 = q1 < 0 ? q1 + W : q1;
+                                u8 *r1 = rch + ((size_t)py * W + q1) * C;
+                                const u8 R0n = mdblend_r0(V, k.c_occ, (u8)md_ld(r0), h.beta);
+                                if (lane == 0) md_st(r0, R0n);
+                                __builtin_amdgcn_s_waitcnt(0);
+                                u8 R1v = (u8)md_ld(r1); // after the r0 store: r1 may alias r0
+                                if (in1) {
+                                    R1v = mdblend_r1(V, k.c_occ, R1v, h.beta);
+                                    if (lane == 0) md_st(r1, R1v);
+                                    __builtin_amdgcn_s_waitcnt(0);
+                                }
+                                const u8 R0v = (r1 == r0) ? R1v : R0n;
+                                const u8 Ln = blend_l_occ(R0v, R1v, h.beta, k.c, (u8)md_ld(lp)); // pyx:330
+                                if (lane == 0) md_st(lp, Ln);
+                            } else {
+                                int q = xd + xw;
+                                q = q < 0 ? q + W : q;
+                                u8 *rd = rch + ((size_t)py * W + q) * C;
+                                const u8 Rn = mdblend1(V, k.c_occ, (u8)md_ld(rd));
+                                const u8 Ln = blend_l_occ_ni(Rn, k.c, (u8)md_ld(lp));    // pyx:333
+                                if (lane == 0) { md_st(rd, Rn); md_st(lp, Ln); }
+                            }
+                        }
+                    } else {                                                           // pyx:334-335
+                        const u8 Ln = mdblend1(V, k.c, (u8)md_ld(lp));
+                        if (lane == 0) md_st(lp, Ln);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0); // stores of this patch pixel land before the next search reads
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 u64 vpp_draws_upper_bound(const VppxVppParams &p, const VppGeom &g)
@@ -644,10 +886,6 @@ static Poly31 qoff_for(u64 rand_offset)
 int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u8 *r, const float *gmap,
                const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev)
 {
-    if (p.method != VPPX_METHOD_RND) {
-        vppx_set_error("maxDistance colour method is not available on the device path in this build");
-        return VPPX_E_UNSUPPORTED;
-    }
     if (g.C < 1 || g.C > 4) { vppx_set_error("channels must be 1..4 (got %d)", g.C); return VPPX_E_INVALID_ARG; }
     if (p.wsize < 1 || p.wsize > 31) { vppx_set_error("wsize must be in 1..31 (got %d)", p.wsize); return VPPX_E_INVALID_ARG; }
     VppK k;
@@ -666,10 +904,32 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     int rc;
     if ((rc = ws_get(ctx, WS_HINT_REC, npx, &k.rec))) return rc;
     if ((rc = ws_get(ctx, WS_HINT_DENSE, npx, &k.dense))) return rc;
+    if ((rc = ws_get(ctx, WS_HINT_X, npx, &k.rng))) return rc;
     if ((rc = ws_get(ctx, WS_ROW_COUNT, (size_t)g.B * g.H, &k.row_count))) return rc;
     if ((rc = ws_get(ctx, WS_ROW_DRAWS, (size_t)g.B * g.H, &k.row_draws))) return rc;
     if ((rc = ws_get(ctx, WS_ROW_BASE, (size_t)g.B * g.H, &k.row_base))) return rc;
     if ((rc = ws_get(ctx, WS_FRAME_TOT, (size_t)g.B * 2, &k.frame_tot))) return rc;
+    if (p.method == VPPX_METHOD_MAXDIST) {
+        if (p.wsize_agg_x < 1 || p.wsize_agg_y < 1) { vppx_set_error("wsize_agg must be >= 1"); return VPPX_E_INVALID_ARG; }
+        if ((rc = ws_get(ctx, WS_HINT_X, npx, &k.rng))) return rc;
+        k.rnd = nullptr;
+        k.rnd_cap = 0;
+        k.uniform = 1; // no random draws: keeps the draw bookkeeping of compact_kernel trivial
+        compact_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
+        VPPX_CHECK_LAUNCH();
+        rowscan_kernel<<<dim3(g.B), 256, 0, ctx->stream>>>(k, (long long *)n_hints_dev);
+        VPPX_CHECK_LAUNCH();
+        stage_mark(ctx, ST_VPP_COMPACT);
+        MdK m;
+        m.k = k;
+        m.k.uniform = p.uniform_color != 0;
+        m.n_agg_x = (p.wsize_agg_x - 1) / 2;
+        m.n_agg_y = (p.wsize_agg_y - 1) / 2;
+        maxdist_kernel<<<dim3(g.B * g.C), 64, 0, ctx->stream>>>(m);
+        VPPX_CHECK_LAUNCH();
+        stage_mark(ctx, ST_VPP_APPLY);
+        return 0;
+    }
     const u64 cap = vpp_draws_upper_bound(p, g);
     u8 *rnd;
     if ((rc = ws_get(ctx, WS_RAND, (size_t)g.B * cap, &rnd))) return rc;

@@ -489,9 +489,11 @@ static int scan_common(vppx_ctx *ctx, VppxVppParams &p, uint8_t *l, uint8_t *r, 
     int64_t nh = 0;
     if ((rc = vppx_vpp_host(ctx, &p, 1, height, width, channels, l, r, g, g_occ, nullptr, &nh))) return rc;
     // advance the libc-like stream by the draws this scan consumed
-    uint64_t draws = 0;
-    if ((rc = vppx_vpp_last_draws(ctx, 1, &draws))) return rc;
-    ctx->rnd_consumed += draws;
+    if (p.method == VPPX_METHOD_RND) { // maxDistance draws nothing from rand()
+        uint64_t draws = 0;
+        if ((rc = vppx_vpp_last_draws(ctx, 1, &draws))) return rc;
+        ctx->rnd_consumed += draws;
+    }
     return (int)nh;
 }
 

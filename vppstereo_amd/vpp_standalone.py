@@ -55,9 +55,10 @@ def vpp(left, right, gt, wsize=3, wsizeAgg_x=64, wsizeAgg_y=3, left2right=True, 
     nh = (C.c_int64 * 1)()
     _lib.check(lib.vppx_vpp_host(ctx.handle, C.byref(p), 1, h, w, ch, _lib.np_ptr(lc), _lib.np_ptr(rc),
                                  _lib.np_ptr(gt), _lib.np_ptr(occ), None, nh))
-    draws = (C.c_uint64 * 1)()
-    _lib.check(lib.vppx_vpp_last_draws(ctx.handle, 1, draws))
-    _stream["consumed"] += int(draws[0])
+    if method == "rnd":  # maxDistance draws nothing from rand()
+        draws = (C.c_uint64 * 1)()
+        _lib.check(lib.vppx_vpp_last_draws(ctx.handle, 1, draws))
+        _stream["consumed"] += int(draws[0])
     return lc, rc
 
 
