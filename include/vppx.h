@@ -188,6 +188,12 @@ int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float
  * context's stream with hipEvents around the kernel only; returns average ms per launch
  * in *ms_out.  Operates on the workspace state left by the last vppx_rsgm_dev call. */
 int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out);
+/* Same for one part of the stage: 1 = horizontal-path line kernel, 2 = the band launches of the
+ * vertical/diagonal paths (fast path only). */
+int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, float *ms_out);
+/* 1 if the last vppx_rsgm_dev call used the band-marching fast path for the 6 non-horizontal
+ * paths, 0 if all 8 paths ran in the line-parallel kernel. */
+int vppx_uses_vert(vppx_ctx *ctx);
 /* Per-stage hipEvent timing of the last vppx_vpp_rsgm_dev/vppx_rsgm_dev call when stage
  * timing is enabled: fills ms[0..n) and returns the number of stages; names via
  * vppx_stage_name(i). */

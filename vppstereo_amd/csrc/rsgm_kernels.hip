@@ -115,6 +115,45 @@ __device__ __forceinline__ void store_words(u32 *p, const u32 (&w)[NW])
     for (; i < NW; i++) p[i] = w[i];
 }
 
+// streaming (read-once) loads
+template <int NW>
+__device__ __forceinline__ void load_words_nt(const u32 *p, u32 (&w)[NW])
+{
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= NW; i += 4) {
+        const u32x4 t = __builtin_nontemporal_load((const u32x4 *)(p + i));
+        w[i] = t.x; w[i + 1] = t.y; w[i + 2] = t.z; w[i + 3] = t.w;
+    }
+#pragma unroll
+    for (; i + 2 <= NW; i += 2) {
+        const u32x2 t = __builtin_nontemporal_load((const u32x2 *)(p + i));
+        w[i] = t.x; w[i + 1] = t.y;
+    }
+#pragma unroll
+    for (; i < NW; i++) w[i] = __builtin_nontemporal_load(p + i);
+}
+
+// streaming stores for write-once volumes: keep them from evicting the census / gray rows that
+// every step re-reads from L2
+template <int NW>
+__device__ __forceinline__ void store_words_nt(u32 *p, const u32 (&w)[NW])
+{
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= NW; i += 4) {
+        u32x4 t = {w[i], w[i + 1], w[i + 2], w[i + 3]};
+        __builtin_nontemporal_store(t, (u32x4 *)(p + i));
+    }
+#pragma unroll
+    for (; i + 2 <= NW; i += 2) {
+        u32x2 t = {w[i], w[i + 1]};
+        __builtin_nontemporal_store(t, (u32x2 *)(p + i));
+    }
+#pragma unroll
+    for (; i < NW; i++) __builtin_nontemporal_store(w[i], p + i);
+}
+
 // ---------------------------------------------------------------------------------------
 // pad (cv2.copyMakeBorder BORDER_REFLECT, rsgm.py:258-260) fused with RGB2GRAY
 // (rsgm.py:11-12): gray(pad(img)) == pad(gray(img)).
@@ -233,7 +272,10 @@ struct PathArgs {
     const u16 *p2lut;
     void *out;
     int Hp, Wp, D, p1;
-    int B, nlb;       // frames, line blocks (16 lines each) per direction
+    int B, nlb;       // frames, line blocks per direction
+    int dir_mask;     // bit k set: run direction k (W,NW,N,NE,E,SE,S,SW)
+    int ndirs;        // popcount(dir_mask)
+    int vol_of_dir[8]; // output volume index of each direction
     size_t vol_elems; // elements per path volume (B*Hp*Wp*D)
 };
 
@@ -374,7 +416,7 @@ __device__ __forceinline__ void store_step(OT *out_f, int pixl, int D, int dbase
         u32 bw[NP / 2];
 #pragma unroll
         for (int i = 0; i + 1 < NP; i += 2) bw[i / 2] = __builtin_amdgcn_perm(L[i + 1], L[i], 0x06040200u);
-        store_words<NP / 2>((u32 *)((u8 *)out_f + off), bw);
+        store_words_nt<NP / 2>((u32 *)((u8 *)out_f + off), bw);
     }
 }
 
@@ -482,7 +524,7 @@ __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
     // the enumeration is XCD-aware: consecutive block ids go round-robin to the 8 XCDs, so frame
     // f is pinned to XCD f % 8 and its census / gray rows stay in one 4 MiB L2.
     const int nlb = a.nlb; // line blocks per direction
-    const int per_frame = nlb * 8;
+    const int per_frame = nlb * a.ndirs;
     int f, within;
     if (a.B % 8 == 0) {
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
@@ -494,7 +536,18 @@ __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
     }
     // long (horizontal) lines first so that they do not form the tail of the launch
     const int dslot = within / nlb, lb = within % nlb;
-    const int dir = (dslot == 0) ? 0 : (dslot == 1 ? 4 : (dslot < 5 ? dslot - 1 : dslot));
+    int dir = 0;
+    {
+        // slot -> direction, in the order 0,4,1,2,3,5,6,7 restricted to the enabled directions
+        const int order[8] = {0, 4, 1, 2, 3, 5, 6, 7};
+        int seen = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool on = (a.dir_mask >> order[i]) & 1;
+            if (on && seen == dslot) dir = order[i];
+            seen += on ? 1 : 0;
+        }
+    }
     const bool horiz = (dir == 0 || dir == 4);
     const int nlines = horiz ? a.Hp : a.Wp;
     if (lb * LPB >= nlines) return;
@@ -525,7 +578,7 @@ __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
     const u32 *cl_f = FROM_DSI ? nullptr : a.cl + fpix;
     const u32 *cr_f = FROM_DSI ? nullptr : a.cr + fpix;
     const u16 *dsi_f = FROM_DSI ? a.dsi + fpix * D : nullptr;
-    OT *out_f = (OT *)a.out + (size_t)dir * a.vol_elems + fpix * D;
+    OT *out_f = (OT *)a.out + (size_t)a.vol_of_dir[dir] * a.vol_elems + fpix * D;
     const bool first = lg == 0, last = lg == GW - 1;
     if (diag)
         run_line<DPL, EXACT, FROM_DSI, OT, true, GW>(gray_f, cl_f, cr_f, dsi_f, out_f, s_lut, Wp, D, x, y, dxs, dys,
@@ -540,7 +593,7 @@ static int launch_paths_t(vppx_ctx *ctx, PathArgs a, int B, bool from_dsi, int e
 {
     constexpr int LPB = 256 / GW;
     a.nlb = ((a.Hp > a.Wp ? a.Hp : a.Wp) + LPB - 1) / LPB;
-    dim3 grid((unsigned)(a.nlb * 8 * B), 1, 1);
+    dim3 grid((unsigned)(a.nlb * a.ndirs * B), 1, 1);
     const bool exact = (a.D == GW * DPL);
     if (from_dsi) {
         if (exact) sgm_paths_kernel<GW, DPL, true, true, u16><<<grid, 256, 0, ctx->stream>>>(a);
@@ -567,9 +620,17 @@ int rsgm_paths_elem_bytes(int D, int maxp2)
 }
 
 int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
-                      const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes)
+                      const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes, int dir_mask)
 {
     PathArgs a;
+    a.dir_mask = dir_mask & 0xFF;
+    a.ndirs = __builtin_popcount(a.dir_mask);
+    if (a.ndirs == 0) return 0;
+    {
+        // all 8 directions: volume k = direction k (oracle path order); a subset is packed densely
+        int nv = 0;
+        for (int k = 0; k < 8; k++) a.vol_of_dir[k] = (a.dir_mask == 0xFF) ? k : (((a.dir_mask >> k) & 1) ? nv++ : 0);
+    }
     a.gray = gray; a.cl = cl; a.cr = cr; a.dsi = dsi; a.p2lut = p2lut; a.out = paths;
     a.Hp = Hp; a.Wp = Wp; a.D = D; a.p1 = p1;
     a.B = B;
@@ -593,6 +654,245 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
         return launch_paths_t<8, 24>(ctx, a, B, from_dsi, elem_bytes);
     }
     return launch_paths_t<8, 32>(ctx, a, B, from_dsi, elem_bytes);
+}
+
+// ---------------------------------------------------------------------------------------
+// Vertical / diagonal paths by band marching (fast path of the fused pipeline).
+// Pass 0 walks the image top-down and carries N, NW, NE; pass 1 walks bottom-up and carries
+// S, SW, SE.  A workgroup owns VT = 64 columns and advances VR = 16 rows per launch; the three
+// paths' state of the previous row lives in LDS as bytes (double buffered), so the three chains
+// that meet in a pixel are summed in registers and ONE byte per cell is stored per pass instead
+// of three path volumes.  Diagonal chains cross strip borders, so a workgroup also recomputes a
+// halo that shrinks by one column per row (columns [x0-15+j, x0+64+15-j) at band row j): no
+// inter-workgroup communication inside a launch; the state of the last band row is handed to
+// the next launch through a small global buffer (double buffered by band parity).
+// Requires byte-sized values: 3*(24 + P2max) <= 255, and D = 16*DPL.
+// ---------------------------------------------------------------------------------------
+#define VT 64
+#define VR 16
+#define VC (VT + 2 * VR) // LDS column slots
+struct VertArgs {
+    const u8 *gray;
+    const u32 *cl;
+    const u32 *cr;
+    const u16 *p2lut;
+    u8 *sv;      // [2 passes][B][Hp][Wp][D] summed paths of a pass
+    u8 *gst;     // [2 parity][2 pass][B][3][Wp][D] state hand-off
+    u16 *gmin;   // [2 parity][2 pass][B][3][Wp]
+    int B, Hp, Wp, D, p1, band;
+    size_t vol_elems; // B*Hp*Wp*D
+};
+
+template <int DPL>
+__global__ void __launch_bounds__(768) sgm_vert_kernel(VertArgs a)
+{
+    constexpr int NP = DPL / 2;
+    constexpr int D = 16 * DPL;
+    constexpr int NW3 = DPL / 4; // dwords of bytes per lane
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    // layout: state[2][3][VC][D] bytes | mins[2][3][VC] u16 | lut[256] u16
+    u8 *st = lds;
+    u16 *mn = (u16 *)(lds + (size_t)2 * 3 * VC * D);
+    u16 *s_lut = mn + 2 * 3 * VC;
+    const int strip = blockIdx.x, pass = blockIdx.y, f = blockIdx.z;
+    const int Wp = a.Wp, Hp = a.Hp;
+    const int x0 = strip * VT;
+    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int dbase = DPL * l16;
+    for (int i = threadIdx.x; i < 256; i += 768) s_lut[i] = a.p2lut[i];
+
+    const size_t fpix = (size_t)f * Hp * Wp;
+    const u8 *gray_f = a.gray + fpix;
+    const u32 *cl_f = a.cl + fpix;
+    const u32 *cr_f = a.cr + fpix;
+    u8 *sv_f = a.sv + (size_t)pass * a.vol_elems + fpix * D;
+    const size_t gst_stride = (size_t)2 * a.B * 3 * Wp; // columns per parity
+    const int par_in = (a.band + 1) & 1, par_out = a.band & 1;
+    const size_t gbase_in = ((size_t)par_in * 2 * a.B + (size_t)pass * a.B + f) * 3 * Wp;
+    const size_t gbase_out = ((size_t)par_out * 2 * a.B + (size_t)pass * a.B + f) * 3 * Wp;
+    (void)gst_stride;
+
+    // ---- load the previous band's last row (columns x0-VR .. x0+VT+VR) into buffer 0 -------------
+    if (a.band > 0) {
+        const int ndw = D / 4;
+        for (int i = threadIdx.x; i < 3 * VC * ndw; i += 768) {
+            const int q = i / (VC * ndw), rem = i % (VC * ndw);
+            const int c = rem / ndw, wdx = rem % ndw;
+            const int x = x0 - VR + c;
+            if (x >= 0 && x < Wp)
+                ((u32 *)(st + ((size_t)(0 * 3 + q) * VC + c) * D))[wdx] = ((const u32 *)(a.gst + (gbase_in + (size_t)q * Wp + x) * D))[wdx];
+        }
+        for (int i = threadIdx.x; i < 3 * VC; i += 768) {
+            const int q = i / VC, c = i % VC;
+            const int x = x0 - VR + c;
+            if (x >= 0 && x < Wp) mn[(0 * 3 + q) * VC + c] = a.gmin[gbase_in + (size_t)q * Wp + x];
+        }
+    }
+    __syncthreads();
+
+    const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
+    const int dy = pass == 0 ? 1 : -1;
+    u32 inact[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) inact[i] = 0;
+
+    // operands of a (row, column) step, fetched one step ahead (global loads are L2 hits but would
+    // otherwise be fully exposed: only 3 waves per SIMD share a CU with this LDS footprint)
+    struct VIn {
+        u32 w[DPL];
+        u32 clv;
+        int I, Ip[3];
+        bool valid;
+    };
+    const int rows_here = min(VR, Hp - a.band * VR);
+    auto vfetch = [&](int sidx, VIn &o) {
+        const int j = sidx >> 1, it = sidx & 1;
+        const int c = j + 1 + g + 48 * it;
+        const int x = x0 - VR + c;
+        const int row = a.band * VR + j;
+        o.valid = (j < rows_here) && !(c > VC - 2 - j || x < 0 || x >= Wp);
+        if (o.valid) {
+            const int y = pass == 0 ? row : Hp - 1 - row;
+            const int pixl = y * Wp + x;
+            load_words<DPL>(cr_f + (pixl - dbase - (DPL - 1)), o.w);
+            o.clv = cl_f[pixl];
+            o.I = gray_f[pixl];
+            if (row > 0) {
+                const u8 *gp = gray_f + (y - dy) * Wp + x;
+                o.Ip[0] = gp[0];
+                o.Ip[1] = x > 0 ? gp[-1] : 0;
+                o.Ip[2] = x < Wp - 1 ? gp[1] : 0;
+            }
+        }
+    };
+    VIn cur, nxt;
+    vfetch(0, cur);
+    for (int sidx = 0; sidx < 2 * rows_here; sidx++) {
+        const int j = sidx >> 1, it = sidx & 1;
+        vfetch(sidx + 1, nxt);
+        const int row = a.band * VR + j;
+        const int y = pass == 0 ? row : Hp - 1 - row;
+        const bool first_row = (row == 0);
+        const int pbuf = j & 1, cbuf = (j + 1) & 1;
+        const int c = j + 1 + g + 48 * it;
+        const int x = x0 - VR + c;
+        if (cur.valid) { // uniform per 16-lane group
+            const int pixl = y * Wp + x;
+            const int I = cur.I;
+            u32 C[NP];
+            {
+                const int lim = x - dbase;
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    u32 c0 = __popc(cur.clv ^ cur.w[DPL - 1 - 2 * i]);
+                    u32 c1 = __popc(cur.clv ^ cur.w[DPL - 2 - 2 * i]);
+                    C[i] = (c1 << 16) | c0;
+                }
+                if (__builtin_amdgcn_ballot_w64(lim < DPL - 1) != 0) {
+#pragma unroll
+                    for (int i = 0; i < NP; i++) {
+                        const u32 lo = (2 * i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
+                        const u32 hi = (2 * i + 1 <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
+                        C[i] = lo | (hi << 16);
+                    }
+                }
+            }
+            u32 acc[NP];
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc[i] = 0;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                // q = 0: straight (N / S), 1: predecessor at x-1 (NW / SW), 2: predecessor at x+1 (NE / SE)
+                const int off = q == 0 ? 0 : (q == 1 ? -1 : 1);
+                const bool reset = first_row || (q == 1 && x == 0) || (q == 2 && x == Wp - 1);
+                u32 L[NP];
+                u32 minpk = 0, P2pk = 0;
+                if (!reset) {
+                    const u32 *sp = (const u32 *)(st + ((size_t)(pbuf * 3 + q) * VC + (c + off)) * D + dbase);
+#pragma unroll
+                    for (int i = 0; i < NW3; i++) {
+                        const u32 bw = sp[i];
+                        L[2 * i] = __builtin_amdgcn_perm(bw, bw, 0x0c010c00u);
+                        L[2 * i + 1] = __builtin_amdgcn_perm(bw, bw, 0x0c030c02u);
+                    }
+                    minpk = pk_splat(mn[(pbuf * 3 + q) * VC + c + off]);
+                    int di = I - cur.Ip[q];
+                    di = di < 0 ? -di : di;
+                    P2pk = pk_splat(s_lut[di]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP; i++) L[i] = 0;
+                }
+                sgm_update<NP, true, 16, false>(L, C, C, C, P1pk, P2pk, minpk, inact, l16 == 0, l16 == 15);
+                u32 *dp = (u32 *)(st + ((size_t)(cbuf * 3 + q) * VC + c) * D + dbase);
+#pragma unroll
+                for (int i = 0; i < NW3; i++) dp[i] = __builtin_amdgcn_perm(L[2 * i + 1], L[2 * i], 0x06040200u);
+                if (l16 == 0) mn[(cbuf * 3 + q) * VC + c] = (u16)(minpk & 0xFFFFu);
+#pragma unroll
+                for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], L[i]);
+            }
+            if (c >= VR && c < VR + VT) { // owned column: one byte per cell for the three paths
+                u32 bw[NW3];
+#pragma unroll
+                for (int i = 0; i < NW3; i++) bw[i] = __builtin_amdgcn_perm(acc[2 * i + 1], acc[2 * i], 0x06040200u);
+                store_words_nt<NW3>((u32 *)(sv_f + (size_t)((u32)pixl * (u32)D + (u32)dbase)), bw);
+            }
+        }
+        if (it == 1) __syncthreads();
+        cur = nxt;
+    }
+    // ---- hand the last row's state of the owned columns to the next band ---------------------------
+    {
+        const int fbuf = rows_here & 1; // buffer written by the last processed row
+        const int ndw = D / 4;
+        for (int i = threadIdx.x; i < 3 * VT * ndw; i += 768) {
+            const int q = i / (VT * ndw), rem = i % (VT * ndw);
+            const int c = VR + rem / ndw, wdx = rem % ndw;
+            const int x = x0 - VR + c;
+            if (x < Wp)
+                ((u32 *)(a.gst + (gbase_out + (size_t)q * Wp + x) * D))[wdx] = ((const u32 *)(st + ((size_t)(fbuf * 3 + q) * VC + c) * D))[wdx];
+        }
+        for (int i = threadIdx.x; i < 3 * VT; i += 768) {
+            const int q = i / VT, c = VR + i % VT;
+            const int x = x0 - VR + c;
+            if (x < Wp) a.gmin[gbase_out + (size_t)q * Wp + x] = mn[(fbuf * 3 + q) * VC + c];
+        }
+    }
+}
+
+bool rsgm_vert_supported(int D, int maxp2) { return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255; }
+
+size_t rsgm_vert_state_bytes(int B, int Wp, int D) { return (size_t)2 * 2 * B * 3 * Wp * D; }
+size_t rsgm_vert_min_elems(int B, int Wp) { return (size_t)2 * 2 * B * 3 * Wp; }
+
+int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
+                     const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u8 *gst, u16 *gmin)
+{
+    VertArgs a;
+    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.gst = gst; a.gmin = gmin;
+    a.B = B; a.Hp = Hp; a.Wp = Wp; a.D = D; a.p1 = p1;
+    a.vol_elems = (size_t)B * Hp * Wp * D;
+    const int nstrips = (Wp + VT - 1) / VT;
+    const int nbands = (Hp + VR - 1) / VR;
+    const size_t ldsb = (size_t)2 * 3 * VC * D + (size_t)2 * 3 * VC * 2 + 512;
+    dim3 grid(nstrips, 2, B);
+#define LAUNCH_V(DPLV)                                                                                        \
+    do {                                                                                                      \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) {                                                                                      \
+            VPPX_HIP(hipFuncSetAttribute((const void *)sgm_vert_kernel<DPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+            attr_set = true;                                                                                  \
+        }                                                                                                     \
+        for (int band = 0; band < nbands; band++) {                                                           \
+            a.band = band;                                                                                    \
+            sgm_vert_kernel<DPLV><<<grid, 768, ldsb, stream>>>(a);                                            \
+        }                                                                                                     \
+    } while (0)
+    if (D == 64) LAUNCH_V(4); else if (D == 128) LAUNCH_V(8); else if (D == 192) LAUNCH_V(12); else LAUNCH_V(16);
+#undef LAUNCH_V
+    VPPX_CHECK_LAUNCH();
+    (void)ctx;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -655,6 +955,7 @@ template <int DPL, bool EXACT, typename IT>
 __global__ void __launch_bounds__(256) sum_wta_kernel(const IT *__restrict__ paths, size_t vol_elems, u16 *__restrict__ S,
                                                       u16 *__restrict__ ST, float *__restrict__ disp, int Hp, int Wp,
                                                       int D, u32 factor_uniq, int do_subpixel)
+// (always sums the 8 per-path volumes: general / stage-API form)
 {
     constexpr int NP = DPL / 2;
     extern __shared__ __attribute__((aligned(16))) u16 tile[]; // [D][66]
@@ -768,10 +1069,14 @@ int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void 
 // the right view (d_R(x) = argmin_d S[x+d][d], needs x .. x+D-1) is read from LDS instead of a
 // second pass over HBM: the path volumes are read once and S is never written.
 // ---------------------------------------------------------------------------------------
-template <int DPL, typename IT>
-__global__ void __launch_bounds__(1024) sum_wta_lr_kernel(const IT *__restrict__ paths, size_t vol_elems,
-                                                          float *__restrict__ disp_l, float *__restrict__ disp_r, int Hp,
-                                                          int Wp, u32 factor_uniq, int do_subpixel)
+struct VolPtrs {
+    const void *v[8];
+};
+
+template <int DPL, typename IT, int NV>
+__global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
+                                                          float *__restrict__ disp_r, int Hp, int Wp, u32 factor_uniq,
+                                                          int do_subpixel)
 {
     constexpr int NP = DPL / 2;
     constexpr int D = 16 * DPL;
@@ -785,13 +1090,13 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(const IT *__restrict__
     const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
     const int dbase = DPL * l16;
     const int ntiles = (Wp + 63) / 64;
-    u32 w[8][NWD]; // operands of the next round, fetched one round ahead
+    u32 w[NV][NWD]; // operands of the next round, fetched one round ahead
     auto fetch = [&](int k) {
         int x = 64 * k + g;
         x = x < Wp ? x : Wp - 1;
         const size_t pix = rowpix + x;
 #pragma unroll
-        for (int v = 0; v < 8; v++) load_words<NWD>((const u32 *)(paths + (size_t)v * vol_elems + pix * D + dbase), w[v]);
+        for (int v = 0; v < NV; v++) load_words_nt<NWD>((const u32 *)((const IT *)vols.v[v] + pix * D + dbase), w[v]);
     };
     fetch(0);
     for (int k = 0; k < ntiles + NR - 1; k++) {
@@ -801,7 +1106,7 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(const IT *__restrict__
 #pragma unroll
             for (int i = 0; i < NP; i++) acc[i] = 0;
 #pragma unroll
-            for (int v = 0; v < 8; v++) {
+            for (int v = 0; v < NV; v++) {
                 if (sizeof(IT) == 2) {
 #pragma unroll
                     for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], w[v][i]);
@@ -848,28 +1153,34 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(const IT *__restrict__
     }
 }
 
-int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, float *disp_l,
-                           float *disp_r, u32 fu, int sub)
+int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
+                           float *disp_l, float *disp_r, u32 fu, int sub)
 {
-    if (D != 64 && D != 128 && D != 192) return 1; // caller falls back to the two-kernel form
+    if ((D != 64 && D != 128 && D != 192) || (nvol != 8 && nvol != 4)) return 1; // caller falls back
     dim3 grid(Hp, B);
-    const size_t vol = (size_t)B * Hp * Wp * D;
     const size_t lds = (size_t)(D / 64 + 2) * D * 66 * sizeof(u16);
-#define LAUNCH_LR(DPLV, T)                                                                                          \
+    VolPtrs vp;
+    for (int i = 0; i < 8; i++) vp.v[i] = i < nvol ? vols[i] : nullptr;
+#define LAUNCH_LR(DPLV, T, NVV)                                                                                     \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPLV, T>,                                  \
+            VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPLV, T, NVV>,                             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        sum_wta_lr_kernel<DPLV, T><<<grid, 1024, lds, ctx->stream>>>((const T *)paths, vol, disp_l, disp_r, Hp, Wp, fu, sub); \
+        sum_wta_lr_kernel<DPLV, T, NVV><<<grid, 1024, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub);      \
+    } while (0)
+#define LAUNCH_LR_D(T, NVV)                                                                                         \
+    do {                                                                                                            \
+        if (D == 64) LAUNCH_LR(4, T, NVV); else if (D == 128) LAUNCH_LR(8, T, NVV); else LAUNCH_LR(12, T, NVV);     \
     } while (0)
     if (elem_bytes == 1) {
-        if (D == 64) LAUNCH_LR(4, u8); else if (D == 128) LAUNCH_LR(8, u8); else LAUNCH_LR(12, u8);
+        if (nvol == 8) LAUNCH_LR_D(u8, 8); else LAUNCH_LR_D(u8, 4);
     } else {
-        if (D == 64) LAUNCH_LR(4, u16); else if (D == 128) LAUNCH_LR(8, u16); else LAUNCH_LR(12, u16);
+        if (nvol == 8) LAUNCH_LR_D(u16, 8); else return 1;
     }
+#undef LAUNCH_LR_D
 #undef LAUNCH_LR
     VPPX_CHECK_LAUNCH();
     return 0;

@@ -5,6 +5,7 @@
 #include "vppx_internal.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 // ---------------------------------------------------------------------------------------
@@ -116,6 +117,17 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         return VPPX_E_HIP;
     }
     ctx->own_stream = true;
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        vppx_set_error("side stream / event creation failed");
+        delete ctx;
+        return VPPX_E_HIP;
+    }
+    {
+        const char *e = getenv("VPPX_VERT");
+        if (e) ctx->use_vert = atoi(e);
+    }
     *out = ctx;
     return 0;
 }
@@ -130,6 +142,9 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (ctx->ev_created)
         for (int i = 0; i <= VPPX_MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 
@@ -284,6 +299,61 @@ static int check_rsgm_params(const VppxRsgmParams &p)
 }
 
 // ---------------------------------------------------------------------------------------
+// 8-path aggregation stage.  which: 0 = everything, 1 = horizontal paths only, 2 = vertical bands
+// only (timing helpers).  Fills vols[] with the volumes the sum/WTA kernel has to add.
+// ---------------------------------------------------------------------------------------
+static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, const u8 *gl, const u32 *cl,
+                           const u32 *cr, const u16 *lut_d, int maxp2, const void **vols, int *nvol_out,
+                           int *elem_bytes_out, int which)
+{
+    int rc;
+    const size_t npp = (size_t)g.B * g.Hp * g.Wp;
+    const size_t ncell = npp * g.D;
+    int nvol;
+    const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
+    const bool vert = ctx->use_vert && elem_bytes == 1 && rsgm_vert_supported(g.D, maxp2) && g.D <= 192;
+    void *paths;
+    if (vert) {
+        // fast path: W/E by line-parallel scan (side stream), N/NW/NE and S/SW/SE by band marching
+        u8 *sv, *gst;
+        u16 *gmin;
+        if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 2, &paths))) return rc;
+        if ((rc = ws_get(ctx, WS_SV, ncell * 2, &sv))) return rc;
+        if ((rc = ws_get(ctx, WS_VSTATE, rsgm_vert_state_bytes(g.B, g.Wp, g.D), &gst))) return rc;
+        if ((rc = ws_get(ctx, WS_VMIN, rsgm_vert_min_elems(g.B, g.Wp), &gmin))) return rc;
+        if (which == 0) {
+            VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->stream2;
+            rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11);
+            ctx->stream = main_stream;
+            if (rc) return rc;
+            VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+            if ((rc = rsgm_launch_vert(ctx, ctx->stream, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, gst, gmin))) return rc;
+            VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        } else if (which == 1) {
+            if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11))) return rc;
+        } else {
+            if ((rc = rsgm_launch_vert(ctx, ctx->stream, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, gst, gmin))) return rc;
+        }
+        vols[0] = paths;
+        vols[1] = (const u8 *)paths + ncell;
+        vols[2] = sv;
+        vols[3] = sv + ncell;
+        nvol = 4;
+    } else {
+        if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * elem_bytes, &paths))) return rc;
+        if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes, 0xFF))) return rc;
+        for (int k = 0; k < 8; k++) vols[k] = (const u8 *)paths + (size_t)k * ncell * elem_bytes;
+        nvol = 8;
+    }
+    *nvol_out = nvol;
+    *elem_bytes_out = elem_bytes;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // rSGM on device buffers (core of compute_rsgm, rsgm.py:250-294)
 // ---------------------------------------------------------------------------------------
 static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, const u8 *left, const u8 *left_vpp,
@@ -315,10 +385,9 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
     VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
     // per-path values are bounded by Cmax + P2max (L_r - min L_r <= P2): bytes suffice when that is < 256
-    const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
-    void *paths;
-    if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * elem_bytes, &paths))) return rc;
-    if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes))) return rc;
+    const void *vols[8];
+    int nvol = 0, elem_bytes = 1;
+    if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0))) return rc;
     stage_mark(ctx, ST_AGGREGATE);
     ctx->last_B = g.B; ctx->last_Hp = g.Hp; ctx->last_Wp = g.Wp; ctx->last_D = g.D; ctx->last_rp = p; ctx->have_last = true;
 
@@ -329,14 +398,14 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_DISP_R1, npp, &dr1))) return rc;
     const u32 fu = uniq_factor(p.uniqueness);
     // rsgm.py:141-142: matchWTA_SSE + subPixelRefine(.., 0) are always applied to the left map
-    rc = rsgm_launch_sum_wta_lr(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, dl0, dr0, fu, 1);
+    rc = rsgm_launch_sum_wta_lr(ctx, g.B, g.Hp, g.Wp, g.D, vols, nvol, elem_bytes, dl0, dr0, fu, 1);
     if (rc < 0) return rc;
     if (rc == 0) {
         stage_mark(ctx, ST_SUM_WTA);
     } else {
         u16 *S;
         if ((rc = ws_get(ctx, WS_S, ncell, &S))) return rc;
-        if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, paths, elem_bytes, nullptr, S, dl0, fu, 1))) return rc;
+        if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, vols[0], elem_bytes, nullptr, S, dl0, fu, 1))) return rc;
         stage_mark(ctx, ST_SUM_WTA);
         if ((rc = rsgm_launch_wta_right_t(ctx, g.B, g.Hp, g.Wp, g.D, S, dr0, fu))) return rc;
         stage_mark(ctx, ST_WTA_RIGHT);
@@ -673,7 +742,7 @@ extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t 
     VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
     if ((rc = ws_reserve(ctx, WS_PATHS, nc * 8 * 2, &paths))) return rc;
     if ((rc = ws_get(ctx, WS_S, nc, &S))) return rc;
-    if ((rc = rsgm_launch_paths(ctx, 1, h, w, dmax, (const u8 *)dimg, nullptr, nullptr, (const u16 *)ddsi, lut_d, p1, paths, 2))) return rc;
+    if ((rc = rsgm_launch_paths(ctx, 1, h, w, dmax, (const u8 *)dimg, nullptr, nullptr, (const u16 *)ddsi, lut_d, p1, paths, 2, 0xFF))) return rc;
     if ((rc = rsgm_launch_sum_wta(ctx, 1, h, w, dmax, paths, 2, S, nullptr, nullptr, 0, 0))) return rc;
     if ((rc = download(ctx, dsi_agg, S, nc * sizeof(u16)))) return rc;
     VPPX_HIP(hipStreamSynchronize(ctx->stream));
@@ -741,7 +810,7 @@ extern "C" int vppx_median3x3(vppx_ctx *ctx, const float *src, float *dst, int w
 // ---------------------------------------------------------------------------------------
 // measurement helper: time the dominant kernel alone with hipEvents on the launch stream
 // ---------------------------------------------------------------------------------------
-extern "C" int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out)
+static int time_aggregation(vppx_ctx *ctx, int iters, int which, float *ms_out)
 {
     int rc;
     if ((rc = check_ctx(ctx))) return rc;
@@ -750,16 +819,19 @@ extern "C" int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out)
     u16 lut_h[256];
     int maxp2;
     p2_lut_host(p, lut_h, &maxp2);
-    const int elem_bytes = rsgm_paths_elem_bytes(ctx->last_D, maxp2);
+    RsgmGeom g;
+    g.B = ctx->last_B; g.Hp = ctx->last_Hp; g.Wp = ctx->last_Wp; g.D = ctx->last_D;
+    g.H = g.Hp; g.W = g.Wp; g.C = 1; g.pad_l = g.pad_r = g.pad_t = g.pad_b = 0;
     hipEvent_t e0, e1;
     VPPX_HIP(hipEventCreate(&e0));
     VPPX_HIP(hipEventCreate(&e1));
-    u32 *cr = (u32 *)ctx->ws[WS_CENSUS_R].p + 512;
+    const u32 *cr = (const u32 *)ctx->ws[WS_CENSUS_R].p + 512;
+    const void *vols[8];
+    int nvol, eb;
     VPPX_HIP(hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < iters; i++) {
-        rc = rsgm_launch_paths(ctx, ctx->last_B, ctx->last_Hp, ctx->last_Wp, ctx->last_D, (const u8 *)ctx->ws[WS_GRAY_L].p,
-                               (const u32 *)ctx->ws[WS_CENSUS_L].p, cr, nullptr, (const u16 *)ctx->ws[WS_P2LUT].p, p.p1,
-                               ctx->ws[WS_PATHS].p, elem_bytes);
+        rc = run_aggregation(ctx, p, g, (const u8 *)ctx->ws[WS_GRAY_L].p, (const u32 *)ctx->ws[WS_CENSUS_L].p, cr,
+                             (const u16 *)ctx->ws[WS_P2LUT].p, maxp2, vols, &nvol, &eb, which);
         if (rc) return rc;
     }
     VPPX_HIP(hipEventRecord(e1, ctx->stream));
@@ -770,4 +842,22 @@ extern "C" int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return 0;
+}
+
+// whole aggregation stage (all launches of the 8 paths) per batch
+extern "C" int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out) { return time_aggregation(ctx, iters, 0, ms_out); }
+// part: 1 = horizontal line kernel only, 2 = vertical band launches only
+extern "C" int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, float *ms_out)
+{
+    if (part != 1 && part != 2) { vppx_set_error("part must be 1 or 2"); return VPPX_E_INVALID_ARG; }
+    return time_aggregation(ctx, iters, part, ms_out);
+}
+// how the aggregation stage of the last call was executed: 1 = band-marching fast path
+extern "C" int vppx_uses_vert(vppx_ctx *ctx)
+{
+    if (!ctx || !ctx->have_last) return 0;
+    u16 lut_h[256];
+    int maxp2;
+    p2_lut_host(ctx->last_rp, lut_h, &maxp2);
+    return (ctx->use_vert && rsgm_paths_elem_bytes(ctx->last_D, maxp2) == 1 && rsgm_vert_supported(ctx->last_D, maxp2) && ctx->last_D <= 192) ? 1 : 0;
 }

@@ -60,6 +60,9 @@ enum WsSlot {
     WS_CENSUS_R,
     WS_PATHS,        // 8 per-path L volumes
     WS_S,            // aggregated volume (u16)
+    WS_SV,           // per-pass sums of the vertical/diagonal paths (band-marching kernel)
+    WS_VSTATE,
+    WS_VMIN,
     WS_DSI,          // materialised cost volume (stage API only)
     WS_DISP_L0,
     WS_DISP_L1,
@@ -89,6 +92,9 @@ struct vppx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr; // side stream: horizontal paths overlap the vertical band launches
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int use_vert = 0;              // VPPX_VERT=1: band-marching kernel for the 6 non-horizontal paths (experimental, slower)
     DevBuf ws[WS_NUM];
     std::string devname;
     // libc-like stream state of the single-frame scans
@@ -151,15 +157,21 @@ int rsgm_launch_cost(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u32 *cl,
 // 8-path aggregation.  Cost source: census pair (dsi == nullptr) or a materialised u16 DSI.
 // Writes the 8 per-path volumes into `paths` (element size elem_bytes = 1 or 2).
 int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
-                      const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes);
+                      const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes, int dir_mask);
+// band-marching vertical/diagonal paths (3 summed paths per pass, one byte per cell)
+bool rsgm_vert_supported(int D, int maxp2);
+size_t rsgm_vert_state_bytes(int B, int Wp, int D);
+size_t rsgm_vert_min_elems(int B, int Wp);
+int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
+                     const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u8 *gst, u16 *gmin);
 // S = sum of the 8 path volumes (+ left WTA, sub-pixel) ; disp_l may be null (stage API: S only)
 int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
                         u16 *ST, float *disp_l, u32 factor_uniq, int do_subpixel);
 int rsgm_launch_wta_right_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *ST, float *disp, u32 factor_uniq);
 int rsgm_paths_elem_bytes(int D, int maxp2);
 // fused sum + left/right WTA; returns 1 (not an error) when the shape is not covered
-int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, float *disp_l,
-                           float *disp_r, u32 factor_uniq, int do_subpixel);
+int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
+                           float *disp_l, float *disp_r, u32 factor_uniq, int do_subpixel);
 int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
 int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp);
 int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);

@@ -95,6 +95,14 @@ class Engine:
         _lib.check(self.lib.vppx_time_aggregate(self.ctx.handle, int(iters), C.byref(ms)))
         return float(ms.value)
 
+    def time_aggregate_part(self, part, iters=10):
+        ms = C.c_float()
+        _lib.check(self.lib.vppx_time_aggregate_part(self.ctx.handle, int(iters), int(part), C.byref(ms)))
+        return float(ms.value)
+
+    def uses_vert(self):
+        return bool(self.lib.vppx_uses_vert(self.ctx.handle))
+
     def enable_stage_timing(self, on=True):
         _lib.check(self.lib.vppx_enable_stage_timing(self.ctx.handle, int(bool(on))))
 
