@@ -130,8 +130,9 @@ def main():
     if rank == 0:
         # ---- dominant kernel, measured live with hipEvents on its own launch stream ----------
         agg_ms = eng.time_aggregate(iters=max(3, min(10, args.steps)))
+        agg_frames = eng.time_aggregate_frames()  # frames per launch (the batch is split over sub-streams)
         Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
-        cells_launch = B * Hp * Wp * D
+        cells_launch = agg_frames * Hp * Wp * D
         achieved = cells_launch * AGG_BYTES_PER_CELL / (agg_ms * 1e-3) / 1e9
         eng.enable_stage_timing(True)
         step()
@@ -151,7 +152,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel_ms": round(agg_ms, 4), "bytes_per_cell": AGG_BYTES_PER_CELL,
-                         "cells_per_launch": cells_launch},
+                         "frames_per_launch": agg_frames, "cells_per_launch": cells_launch},
             "pipeline_roofline": {"bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,
                                   "achieved_GBps": round(pipeline_gbs, 1),
                                   "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4)},

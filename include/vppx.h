@@ -188,6 +188,9 @@ int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float
  * context's stream with hipEvents around the kernel only; returns average ms per launch
  * in *ms_out.  Operates on the workspace state left by the last vppx_rsgm_dev call. */
 int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out);
+/* Frames per launch that vppx_time_aggregate re-runs: vppx_vpp_rsgm_dev splits a batch over
+ * internal sub-streams, and the helper times the launches of one part. */
+int vppx_time_aggregate_frames(vppx_ctx *ctx);
 /* Same for one part of the stage: 1 = horizontal-path line kernel, 2 = the band launches of the
  * vertical/diagonal paths (fast path only). */
 int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, float *ms_out);

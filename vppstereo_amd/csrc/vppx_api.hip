@@ -127,6 +127,8 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
     {
         const char *e = getenv("VPPX_VERT");
         if (e) ctx->use_vert = atoi(e);
+        e = getenv("VPPX_SUBSTREAMS");
+        if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     }
     *out = ctx;
     return 0;
@@ -137,6 +139,10 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (int i = 0; i < 4; i++) {
+        if (ctx->sub[i]) vppx_destroy(ctx->sub[i]);
+        if (ctx->sub_done[i]) (void)hipEventDestroy(ctx->sub_done[i]);
+    }
     for (int i = 0; i < WS_NUM; i++)
         if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
     if (ctx->ev_created)
@@ -174,7 +180,14 @@ extern "C" int vppx_synchronize(vppx_ctx *ctx)
     return 0;
 }
 
-extern "C" size_t vppx_workspace_bytes(const vppx_ctx *ctx) { return ctx ? ctx->total_bytes : 0; }
+extern "C" size_t vppx_workspace_bytes(const vppx_ctx *ctx)
+{
+    if (!ctx) return 0;
+    size_t t = ctx->total_bytes;
+    for (int i = 0; i < 4; i++)
+        if (ctx->sub[i]) t += ctx->sub[i]->total_bytes;
+    return t;
+}
 extern "C" const char *vppx_device_name(const vppx_ctx *ctx) { return ctx ? ctx->devname.c_str() : ""; }
 
 // ---------------------------------------------------------------------------------------
@@ -610,16 +623,11 @@ extern "C" int vppx_rand_stream(vppx_ctx *ctx, uint32_t seed, uint64_t offset, i
 // ---------------------------------------------------------------------------------------
 // fused hot path (test.py:158-225): VPP -> rSGM, batched, device resident
 // ---------------------------------------------------------------------------------------
-extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W,
-                                 int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
-                                 uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
+static int vpp_rsgm_one(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W, int C,
+                        const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ, uint8_t *l_vpp,
+                        uint8_t *r_vpp, float *disp_out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
-    if (!vp || !rp || !left || !right || !g || !disp_out) { vppx_set_error("vppx_vpp_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
-    if ((rc = check_frames(B, H, W, C))) return rc;
-    if ((rc = check_vpp_params(*vp))) return rc;
-    if ((rc = check_rsgm_params(*rp))) return rc;
     const size_t nb = (size_t)B * H * W * C;
     if (!l_vpp && (rc = ws_get(ctx, WS_VPP_L, nb, &l_vpp))) return rc;
     if (!r_vpp && (rc = ws_get(ctx, WS_VPP_R, nb, &r_vpp))) return rc;
@@ -632,6 +640,52 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
     RsgmGeom rg;
     make_geom(B, H, W, C, rp->dmax, rg);
     return rsgm_core(ctx, *rp, rg, left, l_vpp, r_vpp, disp_out);
+}
+
+extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W,
+                                 int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                                 uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!vp || !rp || !left || !right || !g || !disp_out) { vppx_set_error("vppx_vpp_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_frames(B, H, W, C))) return rc;
+    if ((rc = check_vpp_params(*vp))) return rc;
+    if ((rc = check_rsgm_params(*rp))) return rc;
+    const int nsub = (ctx->stage_timing || ctx->is_child) ? 1 : (B >= 2 * ctx->nsub ? ctx->nsub : 1);
+    if (nsub <= 1) return vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+    // Frames are independent: split the batch over child contexts (own stream + arena).  The
+    // latency-bound stages of one part (VPP replay, post-processing) then overlap the
+    // bandwidth-bound stages of another (aggregation stores, sum/WTA loads).
+    for (int i = 0; i < nsub; i++) {
+        if (!ctx->sub[i]) {
+            if ((rc = vppx_create(&ctx->sub[i], ctx->device))) return rc;
+            ctx->sub[i]->is_child = true;
+            ctx->sub[i]->use_vert = ctx->use_vert;
+            VPPX_HIP(hipEventCreateWithFlags(&ctx->sub_done[i], hipEventDisableTiming));
+        }
+    }
+    VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    const size_t fpx = (size_t)H * W;
+    int lo = 0;
+    for (int i = 0; i < nsub; i++) {
+        const int nb = B / nsub + (i < B % nsub ? 1 : 0);
+        vppx_ctx *c = ctx->sub[i];
+        VPPX_HIP(hipStreamWaitEvent(c->stream, ctx->ev_fork, 0));
+        VppxVppParams v2 = *vp;
+        v2.seed = vp->seed + (uint32_t)lo; // frame f keeps srand(seed + f) whatever the split
+        rc = vpp_rsgm_one(c, &v2, rp, nb, H, W, C, left + (size_t)lo * fpx * C, right + (size_t)lo * fpx * C,
+                          g + (size_t)lo * fpx, g_occ ? g_occ + (size_t)lo * fpx : nullptr,
+                          l_vpp ? l_vpp + (size_t)lo * fpx * C : nullptr, r_vpp ? r_vpp + (size_t)lo * fpx * C : nullptr,
+                          disp_out + (size_t)lo * fpx);
+        if (rc) return rc;
+        VPPX_HIP(hipEventRecord(ctx->sub_done[i], c->stream));
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->sub_done[i], 0));
+        lo += nb;
+    }
+    // timing helpers look at the last geometry of the first child
+    ctx->have_last = false;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -814,6 +868,7 @@ static int time_aggregation(vppx_ctx *ctx, int iters, int which, float *ms_out)
 {
     int rc;
     if ((rc = check_ctx(ctx))) return rc;
+    if (!ctx->have_last && ctx->sub[0] && ctx->sub[0]->have_last) ctx = ctx->sub[0]; // batch was split: time one part
     if (!ctx->have_last || iters <= 0 || !ms_out) { vppx_set_error("vppx_time_aggregate: call vppx_rsgm_dev first"); return VPPX_E_INVALID_ARG; }
     const VppxRsgmParams &p = ctx->last_rp;
     u16 lut_h[256];
@@ -852,9 +907,16 @@ extern "C" int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, floa
     if (part != 1 && part != 2) { vppx_set_error("part must be 1 or 2"); return VPPX_E_INVALID_ARG; }
     return time_aggregation(ctx, iters, part, ms_out);
 }
+// frames per launch that vppx_time_aggregate re-runs (a split batch is timed on one part)
+extern "C" int vppx_time_aggregate_frames(vppx_ctx *ctx)
+{
+    if (ctx && !ctx->have_last && ctx->sub[0] && ctx->sub[0]->have_last) ctx = ctx->sub[0];
+    return (ctx && ctx->have_last) ? ctx->last_B : 0;
+}
 // how the aggregation stage of the last call was executed: 1 = band-marching fast path
 extern "C" int vppx_uses_vert(vppx_ctx *ctx)
 {
+    if (ctx && !ctx->have_last && ctx->sub[0] && ctx->sub[0]->have_last) ctx = ctx->sub[0];
     if (!ctx || !ctx->have_last) return 0;
     u16 lut_h[256];
     int maxp2;

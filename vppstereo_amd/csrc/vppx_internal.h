@@ -94,6 +94,12 @@ struct vppx_ctx {
     bool own_stream = false;
     hipStream_t stream2 = nullptr; // side stream: horizontal paths overlap the vertical band launches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // sub-contexts: the fused batched call splits its frames over `nsub` child contexts (own stream
+    // and arena) so that latency-bound stages of one part overlap bandwidth-bound stages of another
+    int nsub = 2;
+    vppx_ctx *sub[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t sub_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool is_child = false;
     int use_vert = 0;              // VPPX_VERT=1: band-marching kernel for the 6 non-horizontal paths (experimental, slower)
     DevBuf ws[WS_NUM];
     std::string devname;

@@ -95,6 +95,9 @@ class Engine:
         _lib.check(self.lib.vppx_time_aggregate(self.ctx.handle, int(iters), C.byref(ms)))
         return float(ms.value)
 
+    def time_aggregate_frames(self):
+        return int(self.lib.vppx_time_aggregate_frames(self.ctx.handle))
+
     def time_aggregate_part(self, part, iters=10):
         ms = C.c_float()
         _lib.check(self.lib.vppx_time_aggregate_part(self.ctx.handle, int(iters), int(part), C.byref(ms)))
