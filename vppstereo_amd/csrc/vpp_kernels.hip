@@ -28,6 +28,7 @@
 #include <mutex>
 
 #define LG 992 // draws per generator thread (32 passes over the 31-word ring)
+#define RLCAP 8 // per-R-pixel hint list capacity (overflow falls back to the row scan)
 
 struct HintRec { // 16 bytes, one per hint, row-compacted in scan order
     int x;
@@ -48,7 +49,9 @@ struct VppK {
     const float *filled; // may be null
     HintRec *rec;        // [B][H][W]
     u32 *rng;            // [B][H][W] per hint: R-target column range lo | hi<<16 (int16 each)
-    uint2 *dense;        // [B][H][W] {idx in row, base in row}
+    uint4 *dense;        // [B][H][W] at hint pixels: {idx in row, base in row, flags, 0}
+    int *rcnt;           // [B][H][W] number of hints that touch an R pixel
+    u32 *rlist;          // [B][H][W][RLCAP] their (row << 16 | idx in row), unordered
     int *row_count;      // [B][H]
     u32 *row_draws;      // [B][H]
     u32 *row_base;       // [B][H]
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
             const u32 occ = (k.occ && k.occ[rowoff + x] != 0) ? 1u : 0u;
             r.flags = occ | ((u32)(nk & 0xFF) << 8) | ((cnt & 0xFFFFu) << 16);
             k.rec[rowoff + my_idx] = r;
-            k.dense[rowoff + x] = make_uint2(my_idx, my_base);
+            k.dense[rowoff + x] = make_uint4(my_idx, my_base, r.flags, 0u);
             // columns of R this hint can touch: [xd0-1-n_k, xd0+n_k] (a negative lo also means the
             // Python-style wraparound write/read of column W-1, SURVEY C-1/C-2)
             int lo = x - (int)floorf(gv) - 1 - nk, hi = x - (int)floorf(gv) + nk;
@@ -549,38 +552,77 @@ __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim
 }
 
 // ---------------------------------------------------------------------------------------
-// 5. R pixels: a block owns 256 consecutive columns of one row; the compact range list of each
-// contributing hint row is staged through LDS (coalesced) and scanned from there.
+// 4b. per-R-pixel hint lists: thread (hint, yw) appends the hint to every R pixel of row y+yw
+// whose column lies in the hint's target range.  Only ~1/3 of the R pixels are touched at all
+// and almost all by one or two hints, so the R kernel replays exactly those instead of scanning
+// whole hint rows.  Lists are unordered (atomics); the consumer sorts by scan rank.
 // ---------------------------------------------------------------------------------------
-#define RCH 1024
+__global__ void __launch_bounds__(256) rlist_kernel(VppK k)
+{
+    const int y = blockIdx.x, f = blockIdx.y;
+    const int W = k.W, H = k.H;
+    const size_t rowoff = ((size_t)f * H + y) * W;
+    const int cnt = k.row_count[(size_t)f * H + y];
+    const int span = 2 * k.n + 1;
+    for (int t = threadIdx.x; t < cnt * span; t += 256) {
+        const int i = t / span, yw = t % span - k.n;
+        const int yp = y + yw;
+        if (yp < 0 || yp > H - 1) continue;
+        const u32 rg = k.rng[rowoff + i];
+        const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
+        const size_t prow = ((size_t)f * H + yp) * W;
+        const u32 id = ((u32)y << 16) | (u32)i;
+        for (int q = max(lo, 0); q <= min(hi, W - 1); q++) {
+            const int slot = atomicAdd(&k.rcnt[prow + q], 1);
+            if (slot < RLCAP) k.rlist[(prow + q) * RLCAP + slot] = id;
+        }
+        if (lo < 0) { // Python-style wraparound target: column W-1 (SURVEY C-1/C-2)
+            if (!(W - 1 >= max(lo, 0) && W - 1 <= hi)) {
+                const int slot = atomicAdd(&k.rcnt[prow + W - 1], 1);
+                if (slot < RLCAP) k.rlist[(prow + W - 1) * RLCAP + slot] = id;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 5. R pixels: one thread per pixel replays the hints of its list in scan order; untouched
+// pixels are not even read.  A list that overflowed (> RLCAP hints on one pixel: very dense
+// hints) falls back to scanning the hint rows.
+// ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
 {
-    __shared__ u32 s_rng[RCH];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int yp = blockIdx.y, f = blockIdx.z;
     const int W = k.W, H = k.H;
-    const bool live = q < W;
-    u8 *px = k.r + (((size_t)f * H + yp) * W + (live ? q : 0)) * k.C;
+    if (q >= W) return;
+    const size_t pidx = ((size_t)f * H + yp) * W + q;
+    const int n = k.rcnt[pidx];
+    if (n == 0) return;
+    u8 *px = k.r + pidx * k.C;
     u8 R[4] = {0, 0, 0, 0};
-    if (live)
-        for (int j = 0; j < k.C; j++) R[j] = px[j];
+    for (int j = 0; j < k.C; j++) R[j] = px[j];
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
-    for (int yy = max(0, yp - k.n); yy <= min(H - 1, yp + k.n); yy++) {
-        const size_t rowoff = ((size_t)f * H + yy) * W;
-        const int cntrow = k.row_count[(size_t)f * H + yy];
-        const u8 *rnd = rnd_f + k.row_base[(size_t)f * H + yy];
-        for (int c0 = 0; c0 < cntrow; c0 += RCH) {
-            const int nc = min(RCH, cntrow - c0);
-            __syncthreads();
-            for (int t = threadIdx.x; t < nc; t += 256) s_rng[t] = k.rng[rowoff + c0 + t];
-            __syncthreads();
-            if (live)
-                for (int t = 0; t < nc; t++)
-                    if (rng_hit(s_rng[t], q, W)) r_apply_hint(k, f, yp, yy, c0 + t, q, R, rnd, 0x7FFFFFFF);
+    if (n <= RLCAP) {
+        u32 ids[RLCAP];
+#pragma unroll
+        for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? k.rlist[pidx * RLCAP + i] : 0xFFFFFFFFu;
+        // scan order = ascending (row, idx in row): sorting network for 8 keys
+#define CS(a, b) { const u32 lo_ = min(ids[a], ids[b]), hi_ = max(ids[a], ids[b]); ids[a] = lo_; ids[b] = hi_; }
+        CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
+        CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
+#undef CS
+#pragma unroll
+        for (int i = 0; i < RLCAP; i++) {
+            if (i < n) {
+                const int yy = (int)(ids[i] >> 16), hi = (int)(ids[i] & 0xFFFFu);
+                r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], 0x7FFFFFFF);
+            }
         }
+    } else {
+        r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
     }
-    if (live)
-        for (int j = 0; j < k.C; j++) px[j] = R[j];
+    for (int j = 0; j < k.C; j++) px[j] = R[j];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -605,10 +647,9 @@ __global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
             const int xx = k.direction ? xa + s : xb - s; // scan order inside the row (pyx:78,129)
             const float gv = k.g[rowoff + xx];
             if (!(gv > 0)) continue;
-            const uint2 dn = k.dense[rowoff + xx];
-            const HintRec rec = k.rec[rowoff + dn.x];
+            const uint4 dn = k.dense[rowoff + xx];
             HintGeo h;
-            decode_hint(xx, gv, rec.base, rec.flags, h);
+            decode_hint(xx, gv, dn.y, dn.z, h);
             const int xw = xp - xx;
             if (yw < -h.nk || yw > h.nk || xw < -h.nk || xw > h.nk) continue;
             if (k.use_bil && !gate_pass(k, f, gv, yp, xp)) continue;
@@ -905,6 +946,8 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     if ((rc = ws_get(ctx, WS_HINT_REC, npx, &k.rec))) return rc;
     if ((rc = ws_get(ctx, WS_HINT_DENSE, npx, &k.dense))) return rc;
     if ((rc = ws_get(ctx, WS_HINT_X, npx, &k.rng))) return rc;
+    k.rcnt = nullptr;
+    k.rlist = nullptr;
     if ((rc = ws_get(ctx, WS_ROW_COUNT, (size_t)g.B * g.H, &k.row_count))) return rc;
     if ((rc = ws_get(ctx, WS_ROW_DRAWS, (size_t)g.B * g.H, &k.row_draws))) return rc;
     if ((rc = ws_get(ctx, WS_ROW_BASE, (size_t)g.B * g.H, &k.row_base))) return rc;
@@ -949,6 +992,11 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     VPPX_CHECK_LAUNCH();
     stage_mark(ctx, ST_VPP_RAND);
     dim3 grid((g.W + 255) / 256, g.H, g.B);
+    if ((rc = ws_get(ctx, WS_RCNT, npx, &k.rcnt))) return rc;
+    if ((rc = ws_get(ctx, WS_RLIST, npx * RLCAP, &k.rlist))) return rc;
+    VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
+    rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
+    VPPX_CHECK_LAUNCH();
     apply_l_kernel<<<grid, 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
     apply_r_kernel<<<grid, 256, 0, ctx->stream>>>(k);

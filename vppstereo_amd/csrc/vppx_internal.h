@@ -43,6 +43,8 @@ enum WsSlot {
     WS_HINT_X = 0,   // compacted hint rows
     WS_HINT_REC,
     WS_HINT_DENSE,
+    WS_RCNT,
+    WS_RLIST,
     WS_ROW_COUNT,
     WS_ROW_DRAWS,
     WS_ROW_BASE,
