@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
+                    help="other BASELINE configs, e.g. --shape 375 1242 192 0.05 (KITTI) or 1536 2048 256 0.01")
     return ap.parse_args()
 
 
@@ -60,12 +62,15 @@ def cpu_baseline(n_frames):
         oracle.compute_rsgm(fr["left"], lv, rv, dmax=D, subpixel=True)
         t_tot += time.perf_counter() - t0
     return dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port",
-                sample=f"{n_frames} full 540x960x192 frames (VPP rnd + rSGM), oracle/liboracle.so gcc -O2, 1 thread, "
+                sample=f"{n_frames} full {H}x{W}x{D} frames (VPP rnd + rSGM), oracle/liboracle.so gcc -O2, 1 thread, "
                        f"{t_tot / n_frames:.2f} s/frame, host has {os.cpu_count()} cpus")
 
 
 def main():
+    global H, W, D, P_HINTS
     args = parse()
+    if args.shape:
+        H, W, D, P_HINTS = int(args.shape[0]), int(args.shape[1]), int(args.shape[2]), float(args.shape[3])
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -142,11 +147,11 @@ def main():
         eng.enable_stage_timing(False)
         pipeline_gbs = value * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / D) / 1e9
         result = {
-            "metric": "Mdisparities/s (HxWxD / s) VPP+rSGM at 540x960xD=192",
+            "metric": f"Mdisparities/s (HxWxD / s) VPP+rSGM at {H}x{W}xD={D}",
             "value": round(value, 1), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": f"540x960 RGB pair, 3% hints, VPP(rnd, wsize 3)+rSGM D=192 subpixel, "
+            "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
                                    f"{B} frames/GPU/step resident in HBM", "frames_per_step": n_total,
                        "H": H, "W": W, "D": D, "hint_density": P_HINTS},
             "roofline": {"bound": "hbm", "kernel": "sgm_paths_kernel (8-path aggregation)",

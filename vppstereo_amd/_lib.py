@@ -73,6 +73,12 @@ def load():
                 f"{LIB_PATH} not found: the HIP library has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C vppstereo_amd/csrc`). "
                 "vppstereo_amd has no CPU fallback.")
+        # torch bundles its own HIP runtime (same soname as /opt/rocm's): whichever is loaded first
+        # serves the whole process, and torch only works with its own -> let torch go first.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         lib.vppx_version.restype = C.c_int

@@ -116,10 +116,17 @@ __device__ __forceinline__ void store_words(u32 *p, const u32 (&w)[NW])
 }
 
 // streaming (read-once) loads
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
 template <int NW>
 __device__ __forceinline__ void load_words_nt(const u32 *p, u32 (&w)[NW])
 {
     int i = 0;
+    if constexpr (NW == 3) { // one global_load_dwordx3
+        typedef u32 u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+        const u32x3a t = __builtin_nontemporal_load((const u32x3a *)p);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z;
+        return;
+    }
 #pragma unroll
     for (; i + 4 <= NW; i += 4) {
         const u32x4 t = __builtin_nontemporal_load((const u32x4 *)(p + i));

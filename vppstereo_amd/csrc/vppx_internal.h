@@ -98,7 +98,8 @@ struct vppx_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // sub-contexts: the fused batched call splits its frames over `nsub` child contexts (own stream
     // and arena) so that latency-bound stages of one part overlap bandwidth-bound stages of another
-    int nsub = 2;
+    int nsub = 1;   // VPPX_SUBSTREAMS=2 overlaps two half batches (+3 %; off by default so that profiles and
+                    // the in-process kernel timing see the same, un-overlapped launches)
     vppx_ctx *sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sub_done[4] = {nullptr, nullptr, nullptr, nullptr};
     bool is_child = false;
