@@ -83,6 +83,12 @@ typedef struct VppxVppParams {
     uint32_t seed;              /*                               [1]                        */
     uint32_t reserved0;
     uint64_t rand_offset;       /*                               [0]                        */
+    /* _bilateral_filling (vpp_standalone.py:372-394, wrapper :419-420): when
+     * use_bilateral_patch is set and no filled_g is passed, the library densifies the hints
+     * itself from the un-patterned left image (BGR2GRAY of it, as the wrapper does at :415) */
+    double bilateral_o_xy;      /*                               [2]                        */
+    double bilateral_o_i;       /*                               [1]                        */
+    double bilateral_th;        /*                               [0.001]                    */
 } VppxVppParams;
 
 /* Parameters of compute_rsgm (rsgm.py:250). */

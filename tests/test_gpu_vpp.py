@@ -198,7 +198,10 @@ def test_vpp_wrapper_matches_oracle_wrapper():
     _, conf_g = vfilter.occlusion_heuristic(fr["hints"])
     assert np.array_equal(conf_o, conf_g)
     for kw in (dict(), dict(g_occ=conf_o, c_occ=0.1), dict(wsize=5, uniform_color=True, left2right=False),
-               dict(wsize=7, use_distance_patch=True, g_occ=conf_o)):
+               dict(wsize=7, use_distance_patch=True, g_occ=conf_o),
+               dict(wsize=7, use_bilateral_patch=True),                       # TPAMI config (README.md:434-437)
+               dict(wsize=5, use_bilateral_patch=True, bilateral_o_xy=3, bilateral_o_i=12, g_occ=conf_o, c_occ=0.2),
+               dict(wsize=5, use_bilateral_patch=True, method="maxDistance", wsizeAgg_x=17)):
         oracle.init_rand(4)
         lo, ro = oracle.vpp(fr["left"], fr["right"], fr["hints"], **kw)
         vpp_standalone.init_rand(4)

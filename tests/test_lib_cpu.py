@@ -31,7 +31,8 @@ def test_param_structs_match_header_defaults():
     r = _lib.rsgm_params()
     assert (r.dmax, r.p1, r.p2min, r.gamma, r.subpixel) == (192, 11, 17, 35, 1)
     assert abs(r.alpha - 0.5) < 1e-7 and abs(r.uniqueness - 0.95) < 1e-7
-    assert C.sizeof(_lib.VppxVppParams) == 80 and C.sizeof(_lib.VppxRsgmParams) == 32
+    assert C.sizeof(_lib.VppxVppParams) == 104 and C.sizeof(_lib.VppxRsgmParams) == 32
+    assert (p.bilateral_o_xy, p.bilateral_o_i, p.bilateral_th) == (2.0, 1.0, 0.001)
 
 
 def _has_gpu():

@@ -1005,6 +1005,68 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// _bilateral_filling (vpp_standalone.py:372-394).  The reference rasters over the hints and lets
+// each stamp its disparity on the window pixels where its weight beats the best so far
+// (`if cmap[n] < weight`, cmap float32, weight float64).  Gather form: one thread per pixel
+// replays, in raster order of the hint positions, the hints whose window covers it, with the
+// same float32 store / float64 compare.  gray = BGR2GRAY of the (RGB) left image, as the
+// wrapper computes it (vpp_standalone.py:415), or the single channel.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gray_ctx_kernel(const u8 *__restrict__ img, u8 *__restrict__ gray, size_t npix, int C)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const u8 *s = img + i * C;
+    gray[i] = C == 3 ? (u8)((s[2] * 9798u + s[1] * 19235u + s[0] * 3735u + 16384u) >> 15) : s[0];
+}
+
+__global__ void __launch_bounds__(256) bilateral_fill_kernel(const float *__restrict__ g, const u8 *__restrict__ gray,
+                                                             float *__restrict__ out, int H, int W, int n, double inv2oxy,
+                                                             double inv2oi, double th)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t base = (size_t)f * H * W;
+    const int In = gray[base + (size_t)y * W + x];
+    float cmap = 0.f;
+    float aug = g[base + (size_t)y * W + x];
+    for (int hy = max(0, y - n); hy <= min(H - 1, y + n); hy++)
+        for (int hx = max(0, x - n); hx <= min(W - 1, x + n); hx++) {
+            const float d_ref = g[base + (size_t)hy * W + hx];
+            if (!(d_ref > 0)) continue;
+            const int yw = y - hy, xw = x - hx;
+            const long long di = (long long)In - (long long)gray[base + (size_t)hy * W + hx];
+            const double a = __dadd_rn(__ddiv_rn((double)(yw * yw + xw * xw), inv2oxy), __ddiv_rn((double)(di * di), inv2oi));
+            const double wgt = exp(-a);
+            if ((double)cmap < wgt) {
+                cmap = (float)wgt;
+                aug = d_ref;
+            }
+        }
+    out[base + (size_t)y * W + x] = ((double)cmap > th) ? aug : 0.f;
+}
+
+int vpp_launch_bilateral_fill(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, const u8 *left, const float *gmap,
+                              float *filled_out)
+{
+    int rc;
+    u8 *gray;
+    const size_t npix = (size_t)g.B * g.H * g.W;
+    if ((rc = ws_get(ctx, WS_GRAY_CTX, npix, &gray))) return rc;
+    gray_ctx_kernel<<<dim3((unsigned)((npix + 255) / 256)), 256, 0, ctx->stream>>>(left, gray, npix, g.C);
+    VPPX_CHECK_LAUNCH();
+    // the reference divides by 2*o^2 (vpp_standalone.py:386); a multiplication by the reciprocal
+    // would round differently, so the kernel receives the divisors
+    dim3 grid((g.W + 255) / 256, g.H, g.B);
+    bilateral_fill_kernel<<<grid, 256, 0, ctx->stream>>>(gmap, gray, filled_out, g.H, g.W, (p.wsize - 1) / 2,
+                                                          2.0 * (p.bilateral_o_xy * p.bilateral_o_xy),
+                                                          2.0 * (p.bilateral_o_i * p.bilateral_o_i), p.bilateral_th);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
 int vpp_launch_rand_stream(vppx_ctx *ctx, u32 seed, u64 offset, int64_t n, int32_t *out_dev)
 {
     if (n <= 0) return 0;

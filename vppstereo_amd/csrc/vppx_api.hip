@@ -39,6 +39,9 @@ extern "C" void vppx_vpp_params_default(VppxVppParams *p)
     p->c_occ = 0.0f;
     p->distance_gamma = 0.3;
     p->seed = 1;
+    p->bilateral_o_xy = 2.0;
+    p->bilateral_o_i = 1.0;
+    p->bilateral_th = 0.001;
 }
 
 extern "C" void vppx_rsgm_params_default(VppxRsgmParams *p)
@@ -509,6 +512,12 @@ extern "C" int vppx_vpp_dev(vppx_ctx *ctx, const VppxVppParams *p, int B, int H,
     if ((rc = check_vpp_params(*p))) return rc;
     VppGeom vg = {B, H, W, C};
     stage_begin(ctx);
+    if (p->use_bilateral_patch && !filled_g) {
+        float *fg;
+        if ((rc = ws_get(ctx, WS_FILLED_G, (size_t)B * H * W, &fg))) return rc;
+        if ((rc = vpp_launch_bilateral_fill(ctx, *p, vg, l, g, fg))) return rc; // l is still un-patterned here
+        filled_g = fg;
+    }
     return vpp_launch(ctx, *p, vg, l, r, g, g_occ, filled_g, n_hints_dev, nullptr);
 }
 
@@ -636,7 +645,14 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmPa
     VPPX_HIP(hipMemcpyAsync(l_vpp, left, nb, hipMemcpyDeviceToDevice, ctx->stream));
     VPPX_HIP(hipMemcpyAsync(r_vpp, right, nb, hipMemcpyDeviceToDevice, ctx->stream));
     VppGeom vg = {B, H, W, C};
-    if ((rc = vpp_launch(ctx, *vp, vg, l_vpp, r_vpp, g, g_occ, nullptr, nullptr, nullptr))) return rc;
+    const float *filled_g = nullptr;
+    if (vp->use_bilateral_patch) {
+        float *fg;
+        if ((rc = ws_get(ctx, WS_FILLED_G, (size_t)B * H * W, &fg))) return rc;
+        if ((rc = vpp_launch_bilateral_fill(ctx, *vp, vg, left, g, fg))) return rc;
+        filled_g = fg;
+    }
+    if ((rc = vpp_launch(ctx, *vp, vg, l_vpp, r_vpp, g, g_occ, filled_g, nullptr, nullptr))) return rc;
     RsgmGeom rg;
     make_geom(B, H, W, C, rp->dmax, rg);
     return rsgm_core(ctx, *rp, rg, left, l_vpp, r_vpp, disp_out);

@@ -44,6 +44,8 @@ enum WsSlot {
     WS_HINT_REC,
     WS_HINT_DENSE,
     WS_RCNT,
+    WS_FILLED_G,
+    WS_GRAY_CTX,
     WS_RLIST,
     WS_ROW_COUNT,
     WS_ROW_DRAWS,
@@ -195,6 +197,9 @@ struct VppGeom {
 };
 int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u8 *r, const float *gmap,
                const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev);
+// _bilateral_filling (vpp_standalone.py:372-394) of the hints g guided by BGR2GRAY(left)
+int vpp_launch_bilateral_fill(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, const u8 *left, const float *gmap,
+                              float *filled_out);
 int vpp_launch_rand_stream(vppx_ctx *ctx, u32 seed, u64 offset, int64_t n, int32_t *out_dev);
 u64 vpp_draws_upper_bound(const VppxVppParams &p, const VppGeom &g);
 

@@ -26,9 +26,6 @@ def vpp(left, right, gt, wsize=3, wsizeAgg_x=64, wsizeAgg_y=3, left2right=True, 
     if np.count_nonzero(gt) == 0:                       # :407 no projection without points
         return lc, rc
 
-    if use_bilateral_patch:
-        raise _lib.VppxError(-10, "use_bilateral_patch (_bilateral_filling, vpp_standalone.py:372) is not part "
-                                  "of this build of the device path")
     pos = gt[gt > 0]
     dmin, dmax = (float(pos.min()), float(pos.max())) if pos.size else (0.0, 0.0)   # :410-411
     if use_distance_patch and not dmax > dmin:
@@ -48,7 +45,9 @@ def vpp(left, right, gt, wsize=3, wsizeAgg_x=64, wsizeAgg_y=3, left2right=True, 
                         wsize_agg_y=int(wsizeAgg_y), direction=direction, uniform_color=int(bool(uniform_color)),
                         discard_occluded=int(bool(discard_occ)), interpolate=int(bool(interpolate)),
                         c=float(blending), c_occ=float(c_occ), use_distance_patch=int(bool(use_distance_patch)),
-                        distance_gamma=float(distance_gamma), dmin=dmin, dmax=dmax)
+                        distance_gamma=float(distance_gamma), dmin=dmin, dmax=dmax,
+                        use_bilateral_patch=int(bool(use_bilateral_patch)), bilateral_o_xy=float(bilateral_o_xy),
+                        bilateral_o_i=float(bilateral_o_i), bilateral_th=float(bilateral_th))
     # continue the libc-like stream shared with vpp_core_opt.init_rand (global state in the reference)
     p.seed = _stream["seed"]
     p.rand_offset = _stream["consumed"]
