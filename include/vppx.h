@@ -168,7 +168,7 @@ int vppx_median3x3(vppx_ctx *ctx, const float *src, float *dst, int w, int h);
 
 /* ---- rSGM: whole compute_rsgm (rsgm.py:250-294), batched -------------------------------- */
 /* left / left_vpp / right_vpp: uint8 [B,H,W,C] (C = 1 or 3); disp_out: float32 [B,H,W].
- * hints / validhints: reserved for --guided (must be NULL in this build). */
+ * hints / validhints: float32 [B,H,W] or both NULL; non-NULL = --guided (_guided_dsi, rsgm.py:116-127). */
 int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,
                    const uint8_t *left_vpp, const uint8_t *right_vpp, const float *hints, const float *validhints,
                    float *disp_out);
@@ -182,6 +182,13 @@ int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, i
 int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W, int C,
                       const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
                       uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out);
+
+/* ---- hand-off to the deep front-ends (test.py:179-200) -------------------------------------- */
+/* uint8 [B,H,W,C] (device) -> [B,C,Hq,Wq] float32 (dst_is_bf16 = 0) or bfloat16 (1) in [0,1]
+ * (value/255. as the reference computes it), replicate-padded up to multiples of
+ * pad_multiple (32 for PSMNet / RAFT-Stereo, test.py:189-198) with lo = pad//2. */
+int vppx_u8_to_nchw_dev(vppx_ctx *ctx, int B, int H, int W, int C, int pad_multiple, const uint8_t *src, void *dst,
+                        int dst_is_bf16);
 
 /* ---- occlusion heuristic (filter.py:246-292): hints -> g_occ mask ------------------------- */
 int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l,

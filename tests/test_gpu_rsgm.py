@@ -109,6 +109,19 @@ def test_compute_rsgm_vs_oracle(H, W, D, C, sub):
         assert np.median(err) < 2.0
 
 
+def test_compute_rsgm_guided_vs_oracle():
+    """--guided: _guided_dsi (rsgm.py:116-127) re-weights the cost rows of the hint pixels."""
+    import vppstereo_amd
+    H, W, D = 50, 116, 64
+    fr = synth.make_frame(H, W, D, 0.06, seed=12)
+    valid = (fr["hints"] > 0).astype(np.float32)
+    want = oracle.compute_rsgm(fr["left"], fr["left"], fr["right"], hints=fr["hints"], validhints=valid, dmax=D)
+    got = vppstereo_amd.compute_rsgm(fr["left"], fr["left"], fr["right"], hints=fr["hints"], validhints=valid, dmax=D)
+    plain = vppstereo_amd.compute_rsgm(fr["left"], fr["left"], fr["right"], dmax=D)
+    assert np.max(np.abs(want - got)) <= TOL and np.array_equal(want, got)
+    assert not np.array_equal(got, plain)
+
+
 def test_fused_batched_hot_path_vs_oracle():
     """vppx_vpp_rsgm_dev (device-resident, batched) == per-frame oracle vpp -> compute_rsgm."""
     import torch
@@ -150,3 +163,32 @@ def test_glue_golden_vectors_through_gpu_pipeline():
     want = oracle.compute_rsgm(l, l, r, dmax=D, subpixel=True)
     got = vppstereo_amd.compute_rsgm(l, l, r, dmax=D, subpixel=True)
     assert np.array_equal(want, got)
+
+
+def test_network_input_handoff_matches_reference_glue():
+    """test.py:179-200: u8 HWC -> /255. -> CHW float -> replicate pad to /32 (and a bf16 variant)."""
+    import torch
+    import torch.nn.functional as F
+    from vppstereo_amd.engine import Engine
+    eng = Engine()
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (2, 37, 50, 3), dtype=np.uint8)
+    a[0, :4, :4] = np.arange(48, dtype=np.uint8).reshape(4, 4, 3)
+    t = torch.from_numpy(a).to(eng.device)
+    got = eng.to_network_input(t).cpu()
+    refs = []
+    for f in range(2):
+        x = torch.from_numpy(a[f] / 255.).permute(2, 0, 1).unsqueeze(0).float()          # test.py:179
+        ht, wt = x.shape[-2:]
+        pad_ht = (((ht // 32) + 1) * 32 - ht) % 32
+        pad_wd = (((wt // 32) + 1) * 32 - wt) % 32
+        pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]       # test.py:189-196
+        refs.append(F.pad(x, pad, mode='replicate'))
+    ref = torch.cat(refs, 0)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    gb = eng.to_network_input(t, dtype=torch.bfloat16).cpu()
+    assert torch.equal(gb, ref.to(torch.bfloat16))
+    # all 256 levels survive the float round trip (SURVEY a19)
+    lv = torch.arange(256, dtype=torch.uint8).reshape(1, 16, 16, 1).to(eng.device)
+    back = (eng.to_network_input(lv, pad_multiple=1).cpu() * 255).numpy().astype(np.uint8).reshape(-1)
+    assert np.array_equal(back, np.arange(256, dtype=np.uint8))

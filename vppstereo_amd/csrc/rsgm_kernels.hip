@@ -199,6 +199,41 @@ int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gr
 }
 
 // ---------------------------------------------------------------------------------------
+// Hand-off to the deep front-ends (test.py:179-200): uint8 HWC -> float NCHW in [0,1]
+// (`img / 255.` in float64, then .float()), replicate-padded to multiples of `mult` with the
+// reference's lo = pad//2, hi = pad - pad//2 split.  Output float32 or bfloat16 (RNE).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) to_nchw_kernel(const u8 *__restrict__ src, void *__restrict__ dst, int H, int W, int C,
+                                                      int Hq, int Wq, int pad_t, int pad_l, int bf16)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int fc = blockIdx.z; // frame * C + channel
+    if (x >= Wq) return;
+    const int f = fc / C, c = fc % C;
+    const int sy = min(max(y - pad_t, 0), H - 1), sx = min(max(x - pad_l, 0), W - 1); // F.pad(mode='replicate')
+    const u8 v = src[(((size_t)f * H + sy) * W + sx) * C + c];
+    const float fv = (float)__ddiv_rn((double)v, 255.0);
+    const size_t o = ((size_t)fc * Hq + y) * Wq + x;
+    if (bf16) {
+        const u32 b = __float_as_uint(fv);
+        ((u16 *)dst)[o] = (u16)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16); // round to nearest even (no NaN/inf here)
+    } else {
+        ((float *)dst)[o] = fv;
+    }
+}
+
+int rsgm_launch_to_nchw(vppx_ctx *ctx, int B, int H, int W, int C, int mult, const u8 *src, void *dst, int bf16)
+{
+    const int pad_h = (((H / mult) + 1) * mult - H) % mult, pad_w = (((W / mult) + 1) * mult - W) % mult;
+    const int Hq = H + pad_h, Wq = W + pad_w;
+    dim3 grid((Wq + 255) / 256, Hq, B * C);
+    to_nchw_kernel<<<grid, 256, 0, ctx->stream>>>(src, dst, H, W, C, Hq, Wq, pad_h / 2, pad_w / 2, bf16);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // census 5x5 (call site rsgm.py:25-26).  24 bits, row-major, first neighbour = bit 23,
 // bit = (neighbour < centre); 2-px border = 0.
 // ---------------------------------------------------------------------------------------
@@ -252,6 +287,35 @@ __global__ void __launch_bounds__(256) cost_kernel(const u32 *__restrict__ cl, c
     u32 c0 = d0 <= x ? __popc(a ^ cr[base + pix - d0]) : INVALID_DISP_COST;
     u32 c1 = d1 <= x ? __popc(a ^ cr[base + pix - d1]) : INVALID_DISP_COST;
     ((u32 *)dsi)[base * (D / 2) + i] = c0 | (c1 << 16);
+}
+
+// _guided_dsi (rsgm.py:116-127, numba): at every hint pixel the cost row is multiplied by
+// k*(1 - exp(-(hint-d)^2 / (2 c^2))), k = 10, c = 1, in float64 and truncated back to uint16.
+// hints / validhints are the un-padded [B,H,W] maps; rsgm.py:266-267 pads them with zeros.
+__global__ void __launch_bounds__(256) guided_dsi_kernel(u16 *__restrict__ dsi, const float *__restrict__ hints,
+                                                         const float *__restrict__ valid, int H, int W, int Hp, int Wp, int D,
+                                                         int pad_t, int pad_l)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t o = ((size_t)f * H + y) * W + x;
+    if (!(valid[o] > 0)) return;
+    const double hv = (double)hints[o];
+    u16 *c = dsi + (((size_t)f * Hp + y + pad_t) * Wp + x + pad_l) * D;
+    for (int d = 0; d < D; d++) {
+        const double diff = __dsub_rn(hv, (double)d);
+        const double t = __dmul_rn(10.0, __dsub_rn(1.0, exp(__ddiv_rn(-__dmul_rn(diff, diff), 2.0))));
+        c[d] = (u16)(int)__dmul_rn((double)c[d], t);
+    }
+}
+
+int rsgm_launch_guided_dsi(vppx_ctx *ctx, const RsgmGeom &g, u16 *dsi, const float *hints, const float *valid)
+{
+    dim3 grid((g.W + 255) / 256, g.H, g.B);
+    guided_dsi_kernel<<<grid, 256, 0, ctx->stream>>>(dsi, hints, valid, g.H, g.W, g.Hp, g.Wp, g.D, g.pad_t, g.pad_l);
+    VPPX_CHECK_LAUNCH();
+    return 0;
 }
 
 int rsgm_launch_cost(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u32 *cl, const u32 *cr, u16 *dsi)

@@ -320,12 +320,27 @@ static int check_rsgm_params(const VppxRsgmParams &p)
 // ---------------------------------------------------------------------------------------
 static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, const u8 *gl, const u32 *cl,
                            const u32 *cr, const u16 *lut_d, int maxp2, const void **vols, int *nvol_out,
-                           int *elem_bytes_out, int which)
+                           int *elem_bytes_out, int which, const float *hints = nullptr, const float *validhints = nullptr)
 {
     int rc;
     const size_t npp = (size_t)g.B * g.Hp * g.Wp;
     const size_t ncell = npp * g.D;
     int nvol;
+    if (hints && validhints) {
+        // --guided (rsgm.py:265-268): like the reference, materialise the cost volume, re-weight the
+        // hint pixels' rows, aggregate from it (costs reach 240: u16 path volumes)
+        u16 *dsi;
+        void *gp;
+        if ((rc = ws_get(ctx, WS_DSI, ncell, &dsi))) return rc;
+        if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * 2, &gp))) return rc;
+        if ((rc = rsgm_launch_cost(ctx, g.B, g.Hp, g.Wp, g.D, cl, cr, dsi))) return rc;
+        if ((rc = rsgm_launch_guided_dsi(ctx, g, dsi, hints, validhints))) return rc;
+        if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, nullptr, nullptr, dsi, lut_d, p.p1, gp, 2, 0xFF))) return rc;
+        for (int k = 0; k < 8; k++) vols[k] = (const u8 *)gp + (size_t)k * ncell * 2;
+        *nvol_out = 8;
+        *elem_bytes_out = 2;
+        return 0;
+    }
     const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
     const bool vert = ctx->use_vert && elem_bytes == 1 && rsgm_vert_supported(g.D, maxp2) && g.D <= 192;
     void *paths;
@@ -373,7 +388,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
 // rSGM on device buffers (core of compute_rsgm, rsgm.py:250-294)
 // ---------------------------------------------------------------------------------------
 static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, const u8 *left, const u8 *left_vpp,
-                     const u8 *right_vpp, float *disp_out)
+                     const u8 *right_vpp, float *disp_out, const float *hints = nullptr, const float *validhints = nullptr)
 {
     int rc;
     const size_t npp = (size_t)g.B * g.Hp * g.Wp;
@@ -403,7 +418,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     // per-path values are bounded by Cmax + P2max (L_r - min L_r <= P2): bytes suffice when that is < 256
     const void *vols[8];
     int nvol = 0, elem_bytes = 1;
-    if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0))) return rc;
+    if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0, hints, validhints))) return rc;
     stage_mark(ctx, ST_AGGREGATE);
     ctx->last_B = g.B; ctx->last_Hp = g.Hp; ctx->last_Wp = g.Wp; ctx->last_D = g.D; ctx->last_rp = p; ctx->have_last = true;
 
@@ -463,11 +478,11 @@ extern "C" int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int 
     if (!p || !left || !left_vpp || !right_vpp || !disp_out) { vppx_set_error("vppx_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_frames(B, H, W, C))) return rc;
     if ((rc = check_rsgm_params(*p))) return rc;
-    if (hints || validhints) { vppx_set_error("--guided (_guided_dsi, rsgm.py:116) is not part of this build"); return VPPX_E_UNSUPPORTED; }
+    if ((hints == nullptr) != (validhints == nullptr)) { hints = nullptr; validhints = nullptr; } // rsgm.py:265 needs both
     RsgmGeom g;
     make_geom(B, H, W, C, p->dmax, g);
     stage_begin(ctx);
-    return rsgm_core(ctx, *p, g, left, left_vpp, right_vpp, disp_out);
+    return rsgm_core(ctx, *p, g, left, left_vpp, right_vpp, disp_out, hints, validhints);
 }
 
 extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,
@@ -484,7 +499,12 @@ extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int
     if ((rc = upload(ctx, WS_STAGE_B, left_vpp, nb, &dlv))) return rc;
     if ((rc = upload(ctx, WS_STAGE_C, right_vpp, nb, &drv))) return rc;
     if ((rc = ws_reserve(ctx, WS_STAGE_D, (size_t)B * H * W * sizeof(float), &dout))) return rc;
-    if ((rc = vppx_rsgm_dev(ctx, p, B, H, W, C, (const u8 *)dl, (const u8 *)dlv, (const u8 *)drv, hints, validhints, (float *)dout))) return rc;
+    void *dh = nullptr, *dv = nullptr;
+    if (hints && validhints) {
+        if ((rc = upload(ctx, WS_STAGE_E, hints, (size_t)B * H * W * sizeof(float), &dh))) return rc;
+        if ((rc = upload(ctx, WS_STAGE_F, validhints, (size_t)B * H * W * sizeof(float), &dv))) return rc;
+    }
+    if ((rc = vppx_rsgm_dev(ctx, p, B, H, W, C, (const u8 *)dl, (const u8 *)dlv, (const u8 *)drv, (const float *)dh, (const float *)dv, (float *)dout))) return rc;
     if ((rc = download(ctx, disp_out, dout, (size_t)B * H * W * sizeof(float)))) return rc;
     VPPX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -702,6 +722,18 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
     // timing helpers look at the last geometry of the first child
     ctx->have_last = false;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// hand-off of the patterned pair to PSMNet / RAFT-Stereo (test.py:179-200)
+// ---------------------------------------------------------------------------------------
+extern "C" int vppx_u8_to_nchw_dev(vppx_ctx *ctx, int B, int H, int W, int C, int pad_multiple, const uint8_t *src,
+                                   void *dst, int dst_is_bf16)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad_multiple <= 0) { vppx_set_error("vppx_u8_to_nchw: bad arguments"); return VPPX_E_INVALID_ARG; }
+    return rsgm_launch_to_nchw(ctx, B, H, W, C, pad_multiple, src, dst, dst_is_bf16 != 0);
 }
 
 // ---------------------------------------------------------------------------------------

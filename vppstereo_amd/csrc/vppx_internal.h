@@ -163,8 +163,10 @@ struct RsgmGeom {
 
 // rsgm_kernels.hip
 int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gray);
+int rsgm_launch_to_nchw(vppx_ctx *ctx, int B, int H, int W, int C, int mult, const u8 *src, void *dst, int bf16);
 int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32 *census);
 int rsgm_launch_cost(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u32 *cl, const u32 *cr, u16 *dsi);
+int rsgm_launch_guided_dsi(vppx_ctx *ctx, const RsgmGeom &g, u16 *dsi, const float *hints, const float *valid);
 // 8-path aggregation.  Cost source: census pair (dsi == nullptr) or a materialised u16 DSI.
 // Writes the 8 per-path volumes into `paths` (element size elem_bytes = 1 or 2).
 int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,

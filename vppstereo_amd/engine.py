@@ -89,6 +89,23 @@ class Engine:
                                                          _ptr(conf)))
         return conf
 
+    def to_network_input(self, img_u8, dtype=None, pad_multiple=32):
+        """Patterned uint8 [B,H,W,C] -> [B,C,Hq,Wq] float32/bfloat16 in [0,1], replicate-padded to
+        multiples of 32: the tensors test.py:179-200 feeds to PSMNet / RAFT-Stereo."""
+        torch = self.torch
+        self._chk(img_u8, torch.uint8, 4, "img")
+        dtype = dtype or torch.float32
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be float32 or bfloat16")
+        B, H, W, Cc = img_u8.shape
+        ph = (((H // pad_multiple) + 1) * pad_multiple - H) % pad_multiple
+        pw = (((W // pad_multiple) + 1) * pad_multiple - W) % pad_multiple
+        out = torch.empty((B, Cc, H + ph, W + pw), dtype=dtype, device=self.device)
+        self._bind_stream()
+        _lib.check(self.lib.vppx_u8_to_nchw_dev(self.ctx.handle, B, H, W, Cc, int(pad_multiple), _ptr(img_u8), _ptr(out),
+                                                int(dtype == torch.bfloat16)))
+        return out
+
     # ---- measurement helpers (bench.py) ----
     def time_aggregate(self, iters=10):
         ms = C.c_float()
