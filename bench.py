@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
@@ -139,6 +139,19 @@ def main():
         Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
         cells_launch = agg_frames * Hp * Wp * D
         achieved = cells_launch * AGG_BYTES_PER_CELL / (agg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH correction
+        # applied); only meaningful for the batch size they were collected at
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("batch") == agg_frames and (H, W, D) == (540, 960, 192):
+                for name, d in pmc["kernels"].items():
+                    if name.startswith("void sgm_paths_kernel") and "hbm_GB_per_launch_corrected" in d:
+                        traffic = d["hbm_GB_per_launch_corrected"]
+        except Exception:
+            traffic = None
         eng.enable_stage_timing(True)
         for _ in range(2):  # first pass sizes the un-split workspace; report the second
             step()
@@ -156,7 +169,9 @@ def main():
                        "H": H, "W": W, "D": D, "hint_density": P_HINTS},
             "roofline": {"bound": "hbm", "kernel": "sgm_paths_kernel (8-path aggregation)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, committed profile)",
+                         "algorithmic_GB_per_launch": round(cells_launch * AGG_BYTES_PER_CELL / 1e9, 3),
                          "kernel_ms": round(agg_ms, 4), "bytes_per_cell": AGG_BYTES_PER_CELL,
                          "frames_per_launch": agg_frames, "cells_per_launch": cells_launch},
             "pipeline_roofline": {"bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,

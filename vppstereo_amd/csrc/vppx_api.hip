@@ -106,7 +106,7 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-        ctx->devname = prop.name;
+        ctx->devname = prop.name[0] ? prop.name : prop.gcnArchName;
         if (strstr(prop.gcnArchName, "gfx950") == nullptr) {
             vppx_set_error("device %d is %s; libvppx is built for gfx950 only", device, prop.gcnArchName);
             delete ctx;
