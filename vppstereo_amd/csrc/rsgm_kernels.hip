@@ -394,8 +394,14 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], con
 #pragma unroll
     for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], t2);
     if (FUSE) {
+        // m += popc(x0) rides on v_bcnt_u32_b32's accumulator operand, the high half on v_lshl_add_u32;
+        // the empty asm keeps the two adds from being re-associated into (lshl_or + add)
 #pragma unroll
-        for (int i = 0; i < NP; i++) m[i] = m[i] + (u32)__popc(X0[i]) + ((u32)__popc(X1[i]) << 16);
+        for (int i = 0; i < NP; i++) {
+            u32 t = (u32)__popc(X0[i]) + m[i];
+            asm volatile("" : "+v"(t));
+            m[i] = ((u32)__popc(X1[i]) << 16) + t;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < NP; i++) m[i] = pk_adds(m[i], C[i]);
