@@ -1,0 +1,106 @@
+"""GPU parity, edge cases and full-size checks of the fused hot path."""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _fused(eng, b, D, seed, occ=None, vpp_kw=None, rsgm_kw=None):
+    import torch
+    dev = eng.device
+    B, H, W, C = b["left"].shape
+    lv = torch.empty((B, H, W, C), dtype=torch.uint8, device=dev)
+    rv = torch.empty_like(lv)
+    kw = dict(dmax=D)
+    kw.update(rsgm_kw or {})
+    out = eng.vpp_rsgm(torch.from_numpy(b["left"]).to(dev), torch.from_numpy(b["right"]).to(dev),
+                       torch.from_numpy(b["hints"]).to(dev), g_occ=None if occ is None else torch.from_numpy(occ).to(dev),
+                       l_vpp=lv, r_vpp=rv, seed=seed, vpp_kw=vpp_kw, rsgm_kw=kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), lv.cpu().numpy(), rv.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from vppstereo_amd.engine import Engine
+    return Engine()
+
+
+@pytest.mark.parametrize("H,W,D,C", [(5, 17, 8, 3), (16, 16, 8, 1), (33, 47, 16, 3), (21, 130, 64, 1), (70, 81, 40, 3),
+                                     (18, 300, 256, 3), (40, 64, 192, 3)])
+def test_odd_shapes_fused_vs_oracle(eng, H, W, D, C):
+    """Frames that are not multiples of 16, narrower than the search range, gray, tiny D."""
+    b = synth.make_batch(2, H, W, max(D, 8), 0.08, seed=H * W, channels=C)
+    out, lv, rv = _fused(eng, b, D, seed=9)
+    for f in range(2):
+        oracle.init_rand(9 + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
+        assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f])
+        l, lo2, ro2 = (b["left"][f][..., 0], lo[..., 0], ro[..., 0]) if C == 1 else (b["left"][f], lo, ro)
+        want = oracle.compute_rsgm(l, lo2, ro2, dmax=D)
+        assert np.array_equal(want, out[f]), float(np.max(np.abs(want - out[f])))
+
+
+def test_no_hints_and_dense_hints(eng):
+    H, W, D = 48, 80, 32
+    b = synth.make_batch(3, H, W, D, 0.05, seed=3)
+    b["hints"][0] = 0                                         # frame without any hint: VPP is the identity
+    b["hints"][1] = np.where(b["gt"][1] > 0, b["gt"][1], 0)   # every pixel is a hint (list overflow fallback)
+    out, lv, rv = _fused(eng, b, D, seed=77, vpp_kw=dict(wsize=5))
+    assert np.array_equal(lv[0], b["left"][0]) and np.array_equal(rv[0], b["right"][0])
+    for f in range(3):
+        oracle.init_rand(77 + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], wsize=5)
+        assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), f
+        assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D), out[f]), f
+
+
+def test_large_penalties_use_u16_volumes(eng):
+    """P2 large enough that path values exceed a byte: the u16-volume variant must agree too."""
+    H, W, D = 40, 96, 64
+    b = synth.make_batch(1, H, W, D, 0.05, seed=8)
+    for kw in (dict(p1=60, p2min=300, gamma=400), dict(p1=20000, p2min=40000, gamma=65000, alpha=3.0)):
+        out, lv, rv = _fused(eng, b, D, seed=1, rsgm_kw=kw)
+        oracle.init_rand(1)
+        lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
+        want = oracle.compute_rsgm(b["left"][0], lo, ro, dmax=D, **kw)
+        assert np.array_equal(want, out[0]), kw
+
+
+def test_full_size_frame_vs_oracle(eng):
+    """BASELINE configuration 540x960, D=192, 3 % hints: bit-exact patterns and disparities."""
+    H, W, D = 540, 960, 192
+    b = synth.make_batch(2, H, W, D, 0.03, seed=1234)
+    hints0 = b["hints"][0]
+    _, conf = oracle.occlusion_heuristic(hints0)
+    occ = np.stack([conf, np.zeros_like(conf)])
+    out, lv, rv = _fused(eng, b, D, seed=1, occ=occ)
+    oracle.init_rand(1)
+    lo, ro = oracle.vpp(b["left"][0], b["right"][0], hints0, g_occ=conf)
+    assert np.array_equal(lo, lv[0]) and np.array_equal(ro, rv[0])
+    want = oracle.compute_rsgm(b["left"][0], lo, ro, dmax=D)
+    assert np.array_equal(want, out[0])
+    err = np.abs(out[0] - b["gt"][0])
+    assert np.median(err) < 1.0 and (err > 3).mean() < 0.25
+    # frame 1 of the batch == the same frame processed alone with its own seed (sharding independence)
+    b1 = {k: v[1:2] for k, v in b.items()}
+    out1, lv1, rv1 = _fused(eng, b1, D, seed=2)
+    assert np.array_equal(out1[0], out[1]) and np.array_equal(lv1[0], lv[1]) and np.array_equal(rv1[0], rv[1])
+
+
+def test_kitti_and_indoor_shapes_properties(eng):
+    """The other BASELINE shapes through size-independent properties: determinism, batch/seed
+    invariance, disparity range, and agreement with the hints at hint pixels."""
+    for (H, W, D, p) in ((375, 1242, 192, 0.05), (768, 1024, 256, 0.01)):
+        b = synth.make_batch(2, H, W, D, p, seed=H)
+        out, lv, rv = _fused(eng, b, D, seed=5)
+        out2, lv2, rv2 = _fused(eng, {k: v[::-1].copy() for k, v in b.items()}, D, seed=5)
+        assert out.shape == (2, H, W) and np.isfinite(out).all() and out.min() >= 0 and out.max() <= D
+        assert not np.array_equal(lv[0], b["left"][0])           # patterns were projected
+        # same frame at another batch position draws from another stream -> different pattern, close disparity
+        assert np.median(np.abs(out[0] - out2[1])) < 0.5
+        err = np.abs(out[0] - b["gt"][0])
+        assert np.median(err) < 1.0
