@@ -628,6 +628,63 @@ __global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
 // ---------------------------------------------------------------------------------------
 // 4. L pixels (must run BEFORE apply_r_kernel: it replays R chains from the original R)
 // ---------------------------------------------------------------------------------------
+// one hint at (yy, xx) acting on L pixel (yp, xp)
+__device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int xp, int yy, int xx, float gv, u8 (&L)[4],
+                                             const u8 *rnd_f)
+{
+    const int W = k.W, H = k.H;
+    const size_t rowoff = ((size_t)f * H + yy) * W;
+    const uint4 dn = k.dense[rowoff + xx];
+    HintGeo h;
+    decode_hint(xx, gv, dn.y, dn.z, h);
+    const int yw = yp - yy, xw = xp - xx;
+    if (yw < -h.nk || yw > h.nk || xw < -h.nk || xw > h.nk) return false;
+    if (k.use_bil && !gate_pass(k, f, gv, yp, xp)) return false;
+    const u8 *rnd = rnd_f + k.row_base[(size_t)f * H + yy];
+    const int idx = k.uniform ? 0 : hint_idx(k, f, yy, xx, gv, h.nk, yw, xw);
+    const int xd0 = xx - h.d0, xd1 = xx - h.d1, xd = xx - h.d;
+    if (0 <= xd0 + xw && xd0 + xw <= W - 1) {                       // pyx:104
+        if (!h.occ) {                                                 // pyx:106-107
+            for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]);
+            return true;
+        } else if (!k.discard) {                                      // pyx:114-122
+            if (k.interp) {
+                const int q0 = xd0 + xw;
+                int q1 = xd1 + xw;
+                q1 = q1 < 0 ? q1 + W : q1;                           // unguarded read, pyx:119
+                u8 R0[4], R1[4];
+                const u8 *r0p = k.r + (((size_t)f * H + yp) * W + q0) * k.C;
+                const u8 *r1p = k.r + (((size_t)f * H + yp) * W + q1) * k.C;
+                for (int j = 0; j < 4; j++) { R0[j] = j < k.C ? r0p[j] : 0; R1[j] = j < k.C ? r1p[j] : 0; }
+                r_chain(k, f, yp, q0, R0, yy, (int)dn.x, xw);
+                if (q1 == q0) {
+                    for (int j = 0; j < 4; j++) R1[j] = R0[j];
+                } else {
+                    r_chain(k, f, yp, q1, R1, yy, (int)dn.x, xw);
+                }
+                for (int j = 0; j < k.C; j++) L[j] = blend_l_occ(R0[j], R1[j], h.beta, k.c, L[j]);
+            } else {
+                int qd = xd + xw;
+                qd = qd < 0 ? qd + W : qd;
+                u8 Rd[4];
+                const u8 *rdp = k.r + (((size_t)f * H + yp) * W + qd) * k.C;
+                for (int j = 0; j < 4; j++) Rd[j] = j < k.C ? rdp[j] : 0;
+                r_chain(k, f, yp, qd, Rd, yy, (int)dn.x, xw);
+                for (int j = 0; j < k.C; j++) L[j] = blend_l_occ_ni(Rd[j], k.c, L[j]);
+            }
+            return true;
+        }
+        return false;
+    }
+    for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]); // pyx:123-124
+    return true;
+}
+
+// NWIN = 2n+1 for n <= 3 (window fits a 64-bit mask): phase A loads the whole window of hint
+// values with independent loads and records, in scan order, which positions hold a hint;
+// phase B visits only those (a wave iterates max-count times, not (2n+1)^2 times).
+// NWIN = 0: generic loop for larger patches.
+template <int NWIN>
 __global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
 {
     const int xp = blockIdx.x * blockDim.x + threadIdx.x;
@@ -635,61 +692,44 @@ __global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
     if (xp >= k.W) return;
     const int W = k.W, H = k.H;
     u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
-    u8 L[4] = {0, 0, 0, 0};
-    for (int j = 0; j < k.C; j++) L[j] = px[j];
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+    const float *gf = k.g + (size_t)f * H * W;
     bool touched = false;
-    for (int yy = max(0, yp - k.n); yy <= min(H - 1, yp + k.n); yy++) {
-        const size_t rowoff = ((size_t)f * H + yy) * W;
-        const int yw = yp - yy;
-        const int xa = max(0, xp - k.n), xb = min(W - 1, xp + k.n);
-        for (int s = 0; s <= xb - xa; s++) {
-            const int xx = k.direction ? xa + s : xb - s; // scan order inside the row (pyx:78,129)
-            const float gv = k.g[rowoff + xx];
-            if (!(gv > 0)) continue;
-            const uint4 dn = k.dense[rowoff + xx];
-            HintGeo h;
-            decode_hint(xx, gv, dn.y, dn.z, h);
-            const int xw = xp - xx;
-            if (yw < -h.nk || yw > h.nk || xw < -h.nk || xw > h.nk) continue;
-            if (k.use_bil && !gate_pass(k, f, gv, yp, xp)) continue;
-            const u8 *rnd = rnd_f + k.row_base[(size_t)f * H + yy];
-            const int idx = k.uniform ? 0 : hint_idx(k, f, yy, xx, gv, h.nk, yw, xw);
-            const int xd0 = xx - h.d0, xd1 = xx - h.d1, xd = xx - h.d;
-            if (0 <= xd0 + xw && xd0 + xw <= W - 1) {                       // pyx:104
-                if (!h.occ) {                                                 // pyx:106-107
-                    for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]);
-                    touched = true;
-                } else if (!k.discard) {                                      // pyx:114-122
-                    if (k.interp) {
-                        const int q0 = xd0 + xw;
-                        int q1 = xd1 + xw;
-                        q1 = q1 < 0 ? q1 + W : q1;                           // unguarded read, pyx:119
-                        u8 R0[4], R1[4];
-                        const u8 *r0p = k.r + (((size_t)f * H + yp) * W + q0) * k.C;
-                        const u8 *r1p = k.r + (((size_t)f * H + yp) * W + q1) * k.C;
-                        for (int j = 0; j < 4; j++) { R0[j] = j < k.C ? r0p[j] : 0; R1[j] = j < k.C ? r1p[j] : 0; }
-                        r_chain(k, f, yp, q0, R0, yy, (int)dn.x, xw);
-                        if (q1 == q0) {
-                            for (int j = 0; j < 4; j++) R1[j] = R0[j];
-                        } else {
-                            r_chain(k, f, yp, q1, R1, yy, (int)dn.x, xw);
-                        }
-                        for (int j = 0; j < k.C; j++) L[j] = blend_l_occ(R0[j], R1[j], h.beta, k.c, L[j]);
-                    } else {
-                        int qd = xd + xw;
-                        qd = qd < 0 ? qd + W : qd;
-                        u8 Rd[4];
-                        const u8 *rdp = k.r + (((size_t)f * H + yp) * W + qd) * k.C;
-                        for (int j = 0; j < 4; j++) Rd[j] = j < k.C ? rdp[j] : 0;
-                        r_chain(k, f, yp, qd, Rd, yy, (int)dn.x, xw);
-                        for (int j = 0; j < k.C; j++) L[j] = blend_l_occ_ni(Rd[j], k.c, L[j]);
-                    }
-                    touched = true;
-                }
-            } else {                                                          // pyx:123-124
-                for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]);
-                touched = true;
+    u8 L[4] = {0, 0, 0, 0};
+    if constexpr (NWIN > 0) {
+        constexpr int n = (NWIN - 1) / 2;
+        unsigned long long mask = 0;
+        float gw[NWIN * NWIN];
+#pragma unroll
+        for (int a = 0; a < NWIN; a++)
+#pragma unroll
+            for (int b = 0; b < NWIN; b++) {
+                const int yy = yp - n + a;
+                const int xx = k.direction ? xp - n + b : xp + n - b; // bit order = scan order (pyx:78,129)
+                const bool in = yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
+                gw[a * NWIN + b] = in ? gf[(size_t)yy * W + xx] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < NWIN * NWIN; i++) mask |= (gw[i] > 0) ? (1ull << i) : 0ull;
+        if (mask == 0) return;
+        for (int j = 0; j < k.C; j++) L[j] = px[j];
+        while (mask) {
+            const int i = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int a = i / NWIN, b = i % NWIN;
+            const int yy = yp - n + a;
+            const int xx = k.direction ? xp - n + b : xp + n - b;
+            touched |= l_apply_hint(k, f, yp, xp, yy, xx, gf[(size_t)yy * W + xx], L, rnd_f);
+        }
+    } else {
+        for (int j = 0; j < k.C; j++) L[j] = px[j];
+        for (int yy = max(0, yp - k.n); yy <= min(H - 1, yp + k.n); yy++) {
+            const int xa = max(0, xp - k.n), xb = min(W - 1, xp + k.n);
+            for (int s2 = 0; s2 <= xb - xa; s2++) {
+                const int xx = k.direction ? xa + s2 : xb - s2; // scan order inside the row (pyx:78,129)
+                const float gv = gf[(size_t)yy * W + xx];
+                if (!(gv > 0)) continue;
+                touched |= l_apply_hint(k, f, yp, xp, yy, xx, gv, L, rnd_f);
             }
         }
     }
@@ -997,7 +1037,13 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
     rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
-    apply_l_kernel<<<grid, 256, 0, ctx->stream>>>(k);
+    switch (k.n) {
+    case 0: apply_l_kernel<1><<<grid, 256, 0, ctx->stream>>>(k); break;
+    case 1: apply_l_kernel<3><<<grid, 256, 0, ctx->stream>>>(k); break;
+    case 2: apply_l_kernel<5><<<grid, 256, 0, ctx->stream>>>(k); break;
+    case 3: apply_l_kernel<7><<<grid, 256, 0, ctx->stream>>>(k); break;
+    default: apply_l_kernel<0><<<grid, 256, 0, ctx->stream>>>(k); break;
+    }
     VPPX_CHECK_LAUNCH();
     apply_r_kernel<<<grid, 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
