@@ -1167,16 +1167,17 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *_
     const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
     const int dbase = DPL * l16;
     const int ntiles = (Wp + 63) / 64;
-    u32 w[NV][NWD]; // operands of the next round, fetched one round ahead
-    auto fetch = [&](int k) {
+    // operands are fetched two rounds ahead into a ping-pong register set: the loads of round k+2
+    // are issued before round k is summed, so two rounds of HBM latency are covered
+    u32 wa[NV][NWD], wb[NV][NWD];
+    auto fetch = [&](int k, u32 (&w)[NV][NWD]) {
         int x = 64 * k + g;
         x = x < Wp ? x : Wp - 1;
         const size_t pix = rowpix + x;
 #pragma unroll
         for (int v = 0; v < NV; v++) load_words_nt<NWD>((const u32 *)((const IT *)vols.v[v] + pix * D + dbase), w[v]);
     };
-    fetch(0);
-    for (int k = 0; k < ntiles + NR - 1; k++) {
+    auto round = [&](int k, u32 (&w)[NV][NWD]) {
         if (k < ntiles) {
             const int x = 64 * k + g;
             u32 acc[NP];
@@ -1195,7 +1196,7 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *_
                     }
                 }
             }
-            if (k + 1 < ntiles) fetch(k + 1); // in flight across the barrier and the right-view phase
+            if (k + 2 < ntiles) fetch(k + 2, w); // this register set is free again
             if (x < Wp) { // uniform per 16-lane group
                 u16 *t = ring + (k % NT) * TS + g;
 #pragma unroll
@@ -1227,6 +1228,12 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *_
                 if (l16 == 0) disp_r[rowpix + xr] = dv;
             }
         }
+    };
+    fetch(0, wa);
+    if (ntiles > 1) fetch(1, wb);
+    for (int k = 0; k < ntiles + NR - 1; k += 2) {
+        round(k, wa);
+        if (k + 1 < ntiles + NR - 1) round(k + 1, wb);
     }
 }
 
