@@ -104,3 +104,15 @@ def test_kitti_and_indoor_shapes_properties(eng):
         assert np.median(np.abs(out[0] - out2[1])) < 0.5
         err = np.abs(out[0] - b["gt"][0])
         assert np.median(err) < 1.0
+
+
+def test_batch_of_eight_uses_xcd_aware_block_map(eng):
+    """B % 8 == 0 switches the aggregation kernel to its XCD-aware block enumeration."""
+    H, W, D = 36, 72, 64
+    b = synth.make_batch(8, H, W, D, 0.06, seed=99)
+    out, lv, rv = _fused(eng, b, D, seed=40)
+    for f in range(8):
+        oracle.init_rand(40 + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
+        assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), f
+        assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D), out[f]), f

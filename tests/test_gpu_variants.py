@@ -1,0 +1,44 @@
+"""GPU parity of the optional execution variants (environment knobs read at context creation):
+the band-marching vertical kernel (VPPX_VERT=1), other lanes-per-pixel layouts (VPPX_GW) and
+sub-stream splitting (VPPX_SUBSTREAMS).  Each variant runs in a fresh process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import oracle, synth
+from vppstereo_amd.engine import Engine
+eng = Engine()
+for (B, H, W, D) in ((4, 50, 150, 192), (8, 40, 96, 64), (2, 70, 81, 128)):
+    b = synth.make_batch(B, H, W, D, 0.05, seed=B * H)
+    dev = eng.device
+    lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev); rv = torch.empty_like(lv)
+    out = eng.vpp_rsgm(torch.from_numpy(b["left"]).to(dev), torch.from_numpy(b["right"]).to(dev),
+                       torch.from_numpy(b["hints"]).to(dev), l_vpp=lv, r_vpp=rv, seed=11, rsgm_kw=dict(dmax=D))
+    torch.cuda.synchronize()
+    out, lv, rv = out.cpu().numpy(), lv.cpu().numpy(), rv.cpu().numpy()
+    for f in range(B):
+        oracle.init_rand(11 + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
+        assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), (B, f)
+        assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D), out[f]), (B, H, W, D, f)
+print("VARIANT_OK", eng.uses_vert())
+""" % ROOT
+
+
+@pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_GW="16"), dict(VPPX_GW="4"), dict(VPPX_SUBSTREAMS="2"),
+                                 dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2")])
+def test_variant_matches_oracle(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    if env.get("VPPX_VERT") == "1":
+        assert "VARIANT_OK True" in r.stdout
