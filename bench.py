@@ -44,26 +44,56 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-parallel", action="store_true", help="also time the CPU port on up to 32 host cores")
     ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
                     help="other BASELINE configs, e.g. --shape 375 1242 192 0.05 (KITTI) or 1536 2048 256 0.01")
     return ap.parse_args()
 
 
-def cpu_baseline(n_frames):
-    """Oracle (CPU restatement of the reference's algorithm), 1 thread, full-size frames."""
+def _cpu_one_frame(f):
+    """VPP (rnd) + rSGM of synthetic frame f with the CPU oracle; returns (seconds, disparity)."""
     import oracle
     import synth
-    t_tot = 0.0
+    fr = synth.make_frame(H, W, D, P_HINTS, seed=1234, frame=f)
+    t0 = time.perf_counter()
+    oracle.init_rand(1 + f)
+    lv, rv = oracle.vpp(fr["left"], fr["right"], fr["hints"])
+    disp = oracle.compute_rsgm(fr["left"], lv, rv, dmax=D, subpixel=True)
+    return time.perf_counter() - t0, disp
+
+
+def _cpu_worker(f):
+    return _cpu_one_frame(f)[0]
+
+
+def cpu_baseline(n_frames, gpu_out=None):
+    """Oracle (CPU restatement of the reference's algorithm), 1 thread, full-size frames -- how the
+    reference runs (rsgm.py:44 numThreads=1, Cython scan single-threaded, test.py:293 batch 1)."""
+    t_tot, epe = 0.0, None
     for f in range(n_frames):
-        fr = synth.make_frame(H, W, D, P_HINTS, seed=1234, frame=f)
-        t0 = time.perf_counter()
-        oracle.init_rand(1 + f)
-        lv, rv = oracle.vpp(fr["left"], fr["right"], fr["hints"])
-        oracle.compute_rsgm(fr["left"], lv, rv, dmax=D, subpixel=True)
-        t_tot += time.perf_counter() - t0
-    return dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port",
+        dt, disp = _cpu_one_frame(f)
+        t_tot += dt
+        if gpu_out is not None and f < gpu_out.shape[0]:
+            e = float(abs(disp - gpu_out[f]).mean())
+            epe = e if epe is None else max(epe, e)
+    base = dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port",
                 sample=f"{n_frames} full {H}x{W}x{D} frames (VPP rnd + rSGM), oracle/liboracle.so gcc -O2, 1 thread, "
                        f"{t_tot / n_frames:.2f} s/frame, host has {os.cpu_count()} cpus")
+    return base, epe
+
+
+def cpu_baseline_parallel(max_procs=32):
+    """Same port, frames in parallel over host cores (one process per frame)."""
+    import multiprocessing as mp
+    n = max(1, min(max_procs, (os.cpu_count() or 1)))
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(n) as pool:
+        per = pool.map(_cpu_worker, list(range(n)))
+    wall = time.perf_counter() - t0
+    return dict(value=n * H * W * D / wall / 1e6, unit="Mdisparities/s", cores=n, kind="port",
+                sample=f"{n} frames on {n} processes, wall {wall:.1f} s (includes frame synthesis), "
+                       f"mean {sum(per) / n:.2f} s/frame/core")
 
 
 def main():
@@ -181,8 +211,12 @@ def main():
             "device": eng.ctx.device_name,
         }
         if world == 1 and args.cpu_frames > 0:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+            gpu_out = out[: min(args.cpu_frames, n_unique)].cpu().numpy()
+            result["cpu_baseline"], epe = cpu_baseline(min(args.cpu_frames, n_unique), gpu_out)
+            result["epe_vs_cpu_oracle"] = epe      # mean |disp_gpu - disp_cpu|, worst frame (0.0 = bit-equal)
             result["speedup_vs_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+            if args.cpu_parallel:
+                result["cpu_baseline_all_cores"] = cpu_baseline_parallel()
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
