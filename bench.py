@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--cpu-parallel", action="store_true", help="also time the CPU port on up to 32 host cores")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
                     help="other BASELINE configs, e.g. --shape 375 1242 192 0.05 (KITTI) or 1536 2048 256 0.01")
     return ap.parse_args()
@@ -99,6 +100,9 @@ def cpu_baseline_parallel(max_procs=32):
 def main():
     global H, W, D, P_HINTS
     args = parse()
+    if os.environ.get("BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_DEBUG"]), exit=True)
     if args.shape:
         H, W, D, P_HINTS = int(args.shape[0]), int(args.shape[1]), int(args.shape[2]), float(args.shape[3])
     import numpy as np
@@ -113,12 +117,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)  # dry runs: several ranks on one GPU
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    eng = Engine(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", dev_index)
+    eng = Engine(dev_index)
 
     B = args.batch
     n_total = B * world
@@ -133,10 +142,14 @@ def main():
     out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     seed0 = vdist.frame_seed(1, lo)
 
-    def step():
+    def local_step():
         eng.vpp_rsgm(left, right, hints, out=out, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1))
+        return out
+
+    def step():
+        local_step()
         if world > 1 and not args.no_gather:
-            return vdist.gather_disparities(out, n_total, dst=0)
+            return vdist.gather_disparities(out, n_total, dst=0)  # collective: every rank calls step() equally often
         return out
 
     for _ in range(args.warmup):
@@ -184,7 +197,7 @@ def main():
             traffic = None
         eng.enable_stage_timing(True)
         for _ in range(2):  # first pass sizes the un-split workspace; report the second
-            step()
+            local_step()    # rank-0-only section: no collectives here
             torch.cuda.synchronize()
         stages = eng.stage_ms()
         eng.enable_stage_timing(False)

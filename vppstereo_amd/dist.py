@@ -38,7 +38,13 @@ def gather_disparities(local_disp, n_frames, dst=0, group=None):
     buf = torch.zeros((bmax, H, W), dtype=local_disp.dtype, device=local_disp.device)
     buf[: local_disp.shape[0]] = local_disp
     parts = [torch.empty_like(buf) for _ in range(ws)]
-    dist.all_gather(parts, buf, group=group)
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:
+        # dry runs without RCCL: stage through the host
+        hparts = [p.cpu() for p in parts]
+        dist.all_gather(hparts, buf.cpu(), group=group)
+        parts = [p.to(buf.device) for p in hparts]
+    else:
+        dist.all_gather(parts, buf, group=group)
     if rank != dst:
         return None
     out = []
