@@ -513,14 +513,22 @@ __device__ __forceinline__ void line_step(LineState<DPL> &st, const StepIn<DPL, 
     constexpr int NP = DPL / 2;
     int di = in.I - st.prevI;
     di = di < 0 ? -di : di;
-    const u32 P2pk = pk_splat(s_lut[di]);
+    u32 P2pk = pk_splat(s_lut[di]);
     if (DIAG) {
-        // chain restart at the image border (missing predecessor => L = C): with L = 0 and min = 0
-        // the update yields exactly C whatever P2 is
-        const u32 keep = (x == wrap_edge) ? 0u : 0xFFFFFFFFu;
+        // chain restart at the image border (missing predecessor => L = C)
+        const bool restart = (x == wrap_edge);
+        if (FROM_DSI) {
+            // arbitrary u16 costs: with L = 0 and min = 0 the update yields exactly C
+            const u32 keep = restart ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < NP; i++) st.L[i] &= keep;
-        st.minpk &= keep;
+            for (int i = 0; i < NP; i++) st.L[i] &= keep;
+            st.minpk &= keep;
+        } else {
+            // census costs (<= 24, no saturation): with P1 = P2 = 0 the minimum term is min_k L_prev(k)
+            // itself, so L = C + min - min = C: two selects instead of zeroing the whole state
+            P1pk = restart ? 0u : P1pk;
+            P2pk = restart ? 0u : P2pk;
+        }
     }
     // byte volumes (no saturation possible) computed from the census pair fuse the cost add into
     // the popcounts; the masked form is only needed where d can exceed x (first D-1 columns).
