@@ -1158,28 +1158,32 @@ struct VolPtrs {
     const void *v[8];
 };
 
-template <int DPL, typename IT, int NV>
-__global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
+// T = pixels per round (= 16-lane groups per block, block = 16*T threads).  SPARE: one extra ring
+// slot lets a single barrier per round suffice; without it (D = 256: LDS is tight) a second barrier
+// separates the right-view reads of round k from the tile write of round k+1.
+template <int DPL, typename IT, int NV, int T, bool SPARE>
+__global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
                                                           float *__restrict__ disp_r, int Hp, int Wp, u32 factor_uniq,
                                                           int do_subpixel)
 {
     constexpr int NP = DPL / 2;
     constexpr int D = 16 * DPL;
-    constexpr int NR = D / 64 + 1;   // tiles a right pixel can touch
-    constexpr int NT = NR + 1;       // ring slots: one spare so that a single barrier per round suffices
-    constexpr int TS = D * 66;       // u16 per tile ([D][66], 2 pad)
+    constexpr int NR = (T + D - 2) / T + 1; // tiles a right pixel can touch (x .. x+D-1)
+    constexpr int NT = NR + (SPARE ? 1 : 0);
+    constexpr int TW = T + 2;               // tile row pitch in u16 (2 pad)
+    constexpr int TS = D * TW;              // u16 per tile
     constexpr int NWD = (sizeof(IT) == 2) ? NP : NP / 2; // dwords per lane per volume
-    extern __shared__ __attribute__((aligned(16))) u16 ring[]; // [NT][D][66]
+    extern __shared__ __attribute__((aligned(16))) u16 ring[]; // [NT][D][TW]
     const int y = blockIdx.x, f = blockIdx.y;
     const size_t rowpix = ((size_t)f * Hp + y) * Wp;
     const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
     const int dbase = DPL * l16;
-    const int ntiles = (Wp + 63) / 64;
+    const int ntiles = (Wp + T - 1) / T;
     // operands are fetched two rounds ahead into a ping-pong register set: the loads of round k+2
     // are issued before round k is summed, so two rounds of HBM latency are covered
     u32 wa[NV][NWD], wb[NV][NWD];
     auto fetch = [&](int k, u32 (&w)[NV][NWD]) {
-        int x = 64 * k + g;
+        int x = T * k + g;
         x = x < Wp ? x : Wp - 1;
         const size_t pix = rowpix + x;
 #pragma unroll
@@ -1187,7 +1191,7 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *_
     };
     auto round = [&](int k, u32 (&w)[NV][NWD]) {
         if (k < ntiles) {
-            const int x = 64 * k + g;
+            const int x = T * k + g;
             u32 acc[NP];
 #pragma unroll
             for (int i = 0; i < NP; i++) acc[i] = 0;
@@ -1209,8 +1213,8 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *_
                 u16 *t = ring + (k % NT) * TS + g;
 #pragma unroll
                 for (int i = 0; i < NP; i++) {
-                    t[(dbase + 2 * i) * 66] = (u16)(acc[i] & 0xFFFFu);
-                    t[(dbase + 2 * i + 1) * 66] = (u16)(acc[i] >> 16);
+                    t[(dbase + 2 * i) * TW] = (u16)(acc[i] & 0xFFFFu);
+                    t[(dbase + 2 * i + 1) * TW] = (u16)(acc[i] >> 16);
                 }
                 const int n = (x < D - 1 ? x : D - 1) + 1;
                 const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
@@ -1220,22 +1224,23 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *_
         __syncthreads();
         const int kr = k - (NR - 1);
         if (kr >= 0) {
-            const int xr = 64 * kr + g;
+            const int xr = T * kr + g;
             if (xr < Wp) {
                 const int n = (Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1;
                 u32 sr[NP];
 #pragma unroll
                 for (int i = 0; i < NP; i++) {
                     const int d0 = dbase + 2 * i, d1 = d0 + 1;
-                    const int xa = xr + d0, xb = xr + d1;
-                    const u32 lo = ring[((xa >> 6) % NT) * TS + d0 * 66 + (xa & 63)];
-                    const u32 hi = ring[((xb >> 6) % NT) * TS + d1 * 66 + (xb & 63)];
+                    const u32 xa = (u32)(xr + d0), xb = (u32)(xr + d1);
+                    const u32 lo = ring[((xa / T) % NT) * TS + d0 * TW + (xa % T)];
+                    const u32 hi = ring[((xb / T) % NT) * TS + d1 * TW + (xb % T)];
                     sr[i] = lo | (hi << 16);
                 }
                 const float dv = wta_rows<DPL>(sr, dbase, n, D, factor_uniq, false, false);
                 if (l16 == 0) disp_r[rowpix + xr] = dv;
             }
         }
+        if (!SPARE) __syncthreads();
     };
     fetch(0, wa);
     if (ntiles > 1) fetch(1, wb);
@@ -1245,37 +1250,47 @@ __global__ void __launch_bounds__(1024) sum_wta_lr_kernel(VolPtrs vols, float *_
     }
 }
 
+template <int DPL, typename IT, int NV, int T, bool SPARE>
+static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
+{
+    constexpr int D = 16 * DPL;
+    constexpr int NR = (T + D - 2) / T + 1;
+    constexpr int NT = NR + (SPARE ? 1 : 0);
+    const size_t lds = (size_t)NT * D * (T + 2) * sizeof(u16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE><<<dim3(Hp, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename IT, int NV>
+static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, int D, float *disp_l, float *disp_r, u32 fu,
+                       int sub)
+{
+    // LDS ring: (tiles) x D x (T+2) u16 must fit 160 KiB
+    if (D == 64) return launch_lr_t<4, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+    if (D == 128) return launch_lr_t<8, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+    if (D == 192) return launch_lr_t<12, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+    return launch_lr_t<16, IT, NV, 32, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub); // D = 256: 153 KiB
+}
+
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
                            float *disp_l, float *disp_r, u32 fu, int sub)
 {
-    if ((D != 64 && D != 128 && D != 192) || (nvol != 8 && nvol != 4)) return 1; // caller falls back
-    dim3 grid(Hp, B);
-    const size_t lds = (size_t)(D / 64 + 2) * D * 66 * sizeof(u16);
+    if ((D != 64 && D != 128 && D != 192 && D != 256) || (nvol != 8 && nvol != 4)) return 1; // caller falls back
     VolPtrs vp;
     for (int i = 0; i < 8; i++) vp.v[i] = i < nvol ? vols[i] : nullptr;
-#define LAUNCH_LR(DPLV, T, NVV)                                                                                     \
-    do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPLV, T, NVV>,                             \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        sum_wta_lr_kernel<DPLV, T, NVV><<<grid, 1024, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub);      \
-    } while (0)
-#define LAUNCH_LR_D(T, NVV)                                                                                         \
-    do {                                                                                                            \
-        if (D == 64) LAUNCH_LR(4, T, NVV); else if (D == 128) LAUNCH_LR(8, T, NVV); else LAUNCH_LR(12, T, NVV);     \
-    } while (0)
     if (elem_bytes == 1) {
-        if (nvol == 8) LAUNCH_LR_D(u8, 8); else LAUNCH_LR_D(u8, 4);
-    } else {
-        if (nvol == 8) LAUNCH_LR_D(u16, 8); else return 1;
+        if (nvol == 8) return launch_lr_d<u8, 8>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub);
+        return launch_lr_d<u8, 4>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub);
     }
-#undef LAUNCH_LR_D
-#undef LAUNCH_LR
-    VPPX_CHECK_LAUNCH();
-    return 0;
+    if (nvol == 8) return launch_lr_d<u16, 8>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub);
+    return 1;
 }
 
 // ---------------------------------------------------------------------------------------
