@@ -1161,10 +1161,13 @@ struct VolPtrs {
 // T = pixels per round (= 16-lane groups per block, block = 16*T threads).  SPARE: one extra ring
 // slot lets a single barrier per round suffice; without it (D = 256: LDS is tight) a second barrier
 // separates the right-view reads of round k from the tile write of round k+1.
+// A block walks `rows_per_block` consecutive rows as ONE stream of rounds (tile j of the stream is
+// tile j % ntiles of row j / ntiles): the operand prefetch and the right view's NR-1 round lag run
+// across row boundaries, so the fill/drain rounds are paid once per block instead of once per row.
 template <int DPL, typename IT, int NV, int T, bool SPARE>
 __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
                                                           float *__restrict__ disp_r, int Hp, int Wp, u32 factor_uniq,
-                                                          int do_subpixel)
+                                                          int do_subpixel, int rows_per_block)
 {
     constexpr int NP = DPL / 2;
     constexpr int D = 16 * DPL;
@@ -1174,24 +1177,36 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
     constexpr int TS = D * TW;              // u16 per tile
     constexpr int NWD = (sizeof(IT) == 2) ? NP : NP / 2; // dwords per lane per volume
     extern __shared__ __attribute__((aligned(16))) u16 ring[]; // [NT][D][TW]
-    const int y = blockIdx.x, f = blockIdx.y;
-    const size_t rowpix = ((size_t)f * Hp + y) * Wp;
+    const int f = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int nrows = (Hp - r0 < rows_per_block) ? Hp - r0 : rows_per_block;
+    const size_t framepix = (size_t)f * Hp * Wp;
     const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
     const int dbase = DPL * l16;
     const int ntiles = (Wp + T - 1) / T;
-    // operands are fetched two rounds ahead into a ping-pong register set: the loads of round k+2
-    // are issued before round k is summed, so two rounds of HBM latency are covered
+    const int total = nrows * ntiles;
+    // stream cursors (uniform): fetch runs two rounds ahead of the left view, the right view NR-1 behind
+    int f_row = r0, f_k = 0;
+    int l_row = r0, l_k = 0, l_slot = 0;
+    int r_row = r0, r_k = 0, r_slot = 0;
+    // operands are fetched two rounds ahead into a ping-pong register set: the loads of round j+2
+    // are issued before round j is summed, so two rounds of HBM latency are covered
     u32 wa[NV][NWD], wb[NV][NWD];
-    auto fetch = [&](int k, u32 (&w)[NV][NWD]) {
-        int x = T * k + g;
+    auto fetch = [&](u32 (&w)[NV][NWD]) {
+        int x = T * f_k + g;
         x = x < Wp ? x : Wp - 1;
-        const size_t pix = rowpix + x;
+        const size_t rowoff = (framepix + (size_t)f_row * Wp) * D; // uniform: scalar base + 32-bit lane offset
+        const u32 laneoff = (u32)x * D + dbase;
 #pragma unroll
-        for (int v = 0; v < NV; v++) load_words_nt<NWD>((const u32 *)((const IT *)vols.v[v] + pix * D + dbase), w[v]);
+        for (int v = 0; v < NV; v++) load_words_nt<NWD>((const u32 *)((const IT *)vols.v[v] + rowoff + laneoff), w[v]);
+        if (++f_k == ntiles) {
+            f_k = 0;
+            f_row++;
+        }
     };
-    auto round = [&](int k, u32 (&w)[NV][NWD]) {
-        if (k < ntiles) {
-            const int x = T * k + g;
+    auto round = [&](int j, u32 (&w)[NV][NWD]) {
+        if (j < total) {
+            const int x = T * l_k + g;
             u32 acc[NP];
 #pragma unroll
             for (int i = 0; i < NP; i++) acc[i] = 0;
@@ -1208,9 +1223,9 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
                     }
                 }
             }
-            if (k + 2 < ntiles) fetch(k + 2, w); // this register set is free again
+            if (j + 2 < total) fetch(w); // this register set is free again
             if (x < Wp) { // uniform per 16-lane group
-                u16 *t = ring + (k % NT) * TS + g;
+                u16 *t = ring + l_slot * TS + g;
 #pragma unroll
                 for (int i = 0; i < NP; i++) {
                     t[(dbase + 2 * i) * TW] = (u16)(acc[i] & 0xFFFFu);
@@ -1218,35 +1233,48 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
                 }
                 const int n = (x < D - 1 ? x : D - 1) + 1;
                 const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
-                if (l16 == 0) disp_l[rowpix + x] = dv;
+                if (l16 == 0) disp_l[framepix + (size_t)l_row * Wp + x] = dv;
+            }
+            l_slot = (l_slot + 1 == NT) ? 0 : l_slot + 1;
+            if (++l_k == ntiles) {
+                l_k = 0;
+                l_row++;
             }
         }
         __syncthreads();
-        const int kr = k - (NR - 1);
-        if (kr >= 0) {
-            const int xr = T * kr + g;
+        if (j >= NR - 1) {
+            const int xr = T * r_k + g;
             if (xr < Wp) {
                 const int n = (Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1;
                 u32 sr[NP];
 #pragma unroll
                 for (int i = 0; i < NP; i++) {
-                    const int d0 = dbase + 2 * i, d1 = d0 + 1;
-                    const u32 xa = (u32)(xr + d0), xb = (u32)(xr + d1);
-                    const u32 lo = ring[((xa / T) % NT) * TS + d0 * TW + (xa % T)];
-                    const u32 hi = ring[((xb / T) % NT) * TS + d1 * TW + (xb % T)];
+                    // S[xr+d][d]: stream tile (g+d)/T past the pixel's own (disparities beyond the row end
+                    // land in the next row's tiles and are masked by n)
+                    const u32 a0 = (u32)(g + dbase + 2 * i), a1 = a0 + 1;
+                    u32 s0 = r_slot + a0 / T, s1 = r_slot + a1 / T;
+                    s0 = s0 >= NT ? s0 - NT : s0;
+                    s1 = s1 >= NT ? s1 - NT : s1;
+                    const u32 lo = ring[s0 * TS + (dbase + 2 * i) * TW + (a0 % T)];
+                    const u32 hi = ring[s1 * TS + (dbase + 2 * i + 1) * TW + (a1 % T)];
                     sr[i] = lo | (hi << 16);
                 }
                 const float dv = wta_rows<DPL>(sr, dbase, n, D, factor_uniq, false, false);
-                if (l16 == 0) disp_r[rowpix + xr] = dv;
+                if (l16 == 0) disp_r[framepix + (size_t)r_row * Wp + xr] = dv;
+            }
+            r_slot = (r_slot + 1 == NT) ? 0 : r_slot + 1;
+            if (++r_k == ntiles) {
+                r_k = 0;
+                r_row++;
             }
         }
         if (!SPARE) __syncthreads();
     };
-    fetch(0, wa);
-    if (ntiles > 1) fetch(1, wb);
-    for (int k = 0; k < ntiles + NR - 1; k += 2) {
-        round(k, wa);
-        if (k + 1 < ntiles + NR - 1) round(k + 1, wb);
+    fetch(wa);
+    if (total > 1) fetch(wb);
+    for (int j = 0; j < total + NR - 1; j += 2) {
+        round(j, wa);
+        if (j + 1 < total + NR - 1) round(j + 1, wb);
     }
 }
 
@@ -1263,7 +1291,12 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE><<<dim3(Hp, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub);
+    // one block per CU is resident (LDS); aim at ~4 equal blocks per CU
+    int chunks = (1024 + B - 1) / B;
+    chunks = chunks < 1 ? 1 : (chunks > Hp ? Hp : chunks);
+    const int rpb = (Hp + chunks - 1) / chunks;
+    chunks = (Hp + rpb - 1) / rpb;
+    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE><<<dim3(chunks, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
     VPPX_CHECK_LAUNCH();
     return 0;
 }
