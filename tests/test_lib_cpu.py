@@ -96,3 +96,11 @@ def test_gt_reshape_matches_oracle():
     n = oracle.lib().vppo_gt_reshape(g.ctypes.data_as(C.POINTER(C.c_float)), 7, 9,
                                      want.ctypes.data_as(C.POINTER(C.c_float)))
     assert np.array_equal(got, want[:n])
+
+
+def test_get_seed_is_wall_clock_seconds():
+    """vpp_core_opt.pyx:23-28: CLOCK_REALTIME seconds as a float."""
+    import time
+    from vppstereo_amd import vpp_core_opt
+    s = vpp_core_opt.get_seed()
+    assert isinstance(s, float) and abs(s - time.time()) < 5.0

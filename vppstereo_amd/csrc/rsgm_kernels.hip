@@ -1292,7 +1292,8 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
         attr_set = true;
     }
     // one block per CU is resident (LDS); aim at ~4 equal blocks per CU
-    int chunks = (1024 + B - 1) / B;
+    static int target = getenv("VPPX_SUM_BLOCKS") ? atoi(getenv("VPPX_SUM_BLOCKS")) : 1024;
+    int chunks = (target + B - 1) / B;
     chunks = chunks < 1 ? 1 : (chunks > Hp ? Hp : chunks);
     const int rpb = (Hp + chunks - 1) / chunks;
     chunks = (Hp + rpb - 1) / rpb;
@@ -1753,8 +1754,18 @@ __global__ void __launch_bounds__(256) speckle_count_kernel(int *__restrict__ la
     const int i = y * W + x;
     // run starts are the only pixels with a run length (runlen is zeroed before every call)
     if (runlen[base + i] <= 0) return;
-    const int r = uf_find(label + base, i);
-    atomicAdd(&count[base + r], runlen[base + i]);
+    // all unions are done: walk to the root with path halving (shortcuts to an ancestor are benign
+    // under concurrency) and leave the run start pointing at the root for the apply pass
+    int *lb = label + base;
+    int c = i, p = lb[c];
+    while (p != c) {
+        const int gp = lb[p];
+        if (gp != p) lb[c] = gp;
+        c = gp;
+        p = lb[c];
+    }
+    if (c != i) lb[i] = c;
+    atomicAdd(&count[base + c], runlen[base + i]);
 }
 
 __global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict__ fd8, int *__restrict__ label,
@@ -1780,49 +1791,73 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict
 // _interpolate_background rows (rsgm.py:189-214).  Fills only touch invalid (<= 0) pixels and
 // read only originally valid ones, so per pixel: nearest valid to the left (xl) and to the
 // right (xr) of the ORIGINAL row; both -> min(v[xl], v[xr]); only one -> that one (border
-// extension); none -> unchanged.  Nearest-valid indices by Hillis-Steele max/min scans in LDS.
+// extension); none -> unchanged.  Each thread owns a contiguous segment of the row; the nearest
+// valid index outside the segment comes from one wave-level max/min scan (+ 4 wave carries).
 __global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__ dm, int H, int W)
 {
-    extern __shared__ __attribute__((aligned(16))) int sh[]; // [2][W] nearest-valid indices, then [W] floats
-    int *il = sh, *ir = sh + W;
-    float *val = (float *)(sh + 2 * W);
+    extern __shared__ __attribute__((aligned(16))) float sh_f[]; // [W] original row, [W] result
+    __shared__ int s_l[4], s_r[4];
+    float *val = sh_f, *res = sh_f + W;
     const int y = blockIdx.x, f = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *g = dm + ((size_t)f * H + y) * W;
-    for (int x = threadIdx.x; x < W; x += 256) {
-        const float v = g[x];
-        val[x] = v;
-        il[x] = v > 0 ? x : -1;
-        ir[x] = v > 0 ? x : 0x7FFFFFFF;
-    }
+    for (int x = threadIdx.x; x < W; x += 256) val[x] = g[x];
     __syncthreads();
-    for (int s = 1; s < W; s <<= 1) {
-        int tl[8], tr[8]; // W <= 2048 with 256 threads
-        int k = 0;
-        for (int x = threadIdx.x; x < W; x += 256, k++) {
-            tl[k] = x - s >= 0 ? max(il[x], il[x - s]) : il[x];
-            tr[k] = x + s < W ? min(ir[x], ir[x + s]) : ir[x];
+    const int SEG = (W + 255) / 256; // <= 8 (W <= 2048)
+    const int x0 = threadIdx.x * SEG;
+    int lastv = -1, firstv = 0x7FFFFFFF;
+    for (int j = 0; j < SEG; j++) {
+        const int x = x0 + j;
+        if (x < W && val[x] > 0) {
+            lastv = x;
+            if (firstv == 0x7FFFFFFF) firstv = x;
         }
-        __syncthreads();
-        k = 0;
-        for (int x = threadIdx.x; x < W; x += 256, k++) { il[x] = tl[k]; ir[x] = tr[k]; }
-        __syncthreads();
     }
-    for (int x = threadIdx.x; x < W; x += 256) {
+    int sl = lastv, sr = firstv;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int tl = __shfl_up(sl, off), tr = __shfl_down(sr, off);
+        if (lane >= off) sl = max(sl, tl);
+        if (lane + off < 64) sr = min(sr, tr);
+    }
+    if (lane == 63) s_l[wv] = sl;
+    if (lane == 0) s_r[wv] = sr;
+    __syncthreads();
+    int cl = __shfl_up(sl, 1), cr = __shfl_down(sr, 1);
+    if (lane == 0) cl = -1;
+    if (lane == 63) cr = 0x7FFFFFFF;
+    for (int w = 0; w < wv; w++) cl = max(cl, s_l[w]);
+    for (int w = wv + 1; w < 4; w++) cr = min(cr, s_r[w]);
+    int xl[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int x = x0 + j;
+        if (j < SEG && x < W && val[x] > 0) cl = x;
+        xl[j] = cl;
+    }
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+        const int x = x0 + j;
+        if (j >= SEG || x >= W) continue;
         float v = val[x];
-        if (!(v > 0)) {
-            const int xl = il[x], xr = ir[x];
-            const bool hl = xl >= 0, hr = xr < W;
+        if (v > 0) {
+            cr = x;
+        } else {
+            const bool hl = xl[j] >= 0, hr = cr < W;
             if (hl && hr) {
-                const float a = val[xl], b = val[xr];
+                const float a = val[xl[j]], b = val[cr];
                 v = b < a ? b : a; // Python min(a, b)
             } else if (hr) {
-                v = val[xr];
+                v = val[cr];
             } else if (hl) {
-                v = val[xl];
+                v = val[xl[j]];
             }
-            g[x] = v;
         }
+        res[x] = v;
     }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256)
+        if (!(val[x] > 0)) g[x] = res[x];
 }
 // columns (rsgm.py:216-227): per column, rows above the first valid row take its value, rows
 // below the last valid row take that one's.  Block = 64 columns x 4 row-lanes.
@@ -1867,7 +1902,7 @@ int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, cons
     VPPX_CHECK_LAUNCH();
     speckle_apply_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, lcount, fdc, out, g.H, g.W, 0, 200, subpixel);
     VPPX_CHECK_LAUNCH();
-    interp_bg_rows_kernel<<<dim3(g.H, g.B), 256, (size_t)g.W * 3 * sizeof(int), ctx->stream>>>(out, g.H, g.W);
+    interp_bg_rows_kernel<<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();
     interp_bg_cols_kernel<<<dim3((g.W + 63) / 64, g.B), 256, 0, ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();

@@ -552,8 +552,8 @@ __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim
 }
 
 // ---------------------------------------------------------------------------------------
-// 4b. per-R-pixel hint lists: thread (hint, yw) appends the hint to every R pixel of row y+yw
-// whose column lies in the hint's target range.  Only ~1/3 of the R pixels are touched at all
+// 4b. per-R-pixel hint lists: thread (hint, yw, target column) appends the hint to the R pixel of
+// row y+yw at that column of the hint's target range.  Only ~1/3 of the R pixels are touched at all
 // and almost all by one or two hints, so the R kernel replays exactly those instead of scanning
 // whole hint rows.  Lists are unordered (atomics); the consumer sorts by scan rank.
 // ---------------------------------------------------------------------------------------
@@ -563,20 +563,22 @@ __global__ void __launch_bounds__(256) rlist_kernel(VppK k)
     const int W = k.W, H = k.H;
     const size_t rowoff = ((size_t)f * H + y) * W;
     const int cnt = k.row_count[(size_t)f * H + y];
-    const int span = 2 * k.n + 1;
-    for (int t = threadIdx.x; t < cnt * span; t += 256) {
-        const int i = t / span, yw = t % span - k.n;
+    const int span = 2 * k.n + 1, tw = 2 * k.n + 2; // rows of the patch, columns of the target range
+    for (int t = threadIdx.x; t < cnt * span * tw; t += 256) {
+        const int i = t / (span * tw), rem = t % (span * tw);
+        const int yw = rem / tw - k.n, tq = rem % tw;
         const int yp = y + yw;
         if (yp < 0 || yp > H - 1) continue;
         const u32 rg = k.rng[rowoff + i];
         const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
         const size_t prow = ((size_t)f * H + yp) * W;
         const u32 id = ((u32)y << 16) | (u32)i;
-        for (int q = max(lo, 0); q <= min(hi, W - 1); q++) {
+        const int q = lo + tq;
+        if (q >= 0 && q <= hi && q <= W - 1) {
             const int slot = atomicAdd(&k.rcnt[prow + q], 1);
             if (slot < RLCAP) k.rlist[(prow + q) * RLCAP + slot] = id;
         }
-        if (lo < 0) { // Python-style wraparound target: column W-1 (SURVEY C-1/C-2)
+        if (tq == 0 && lo < 0) { // Python-style wraparound target: column W-1 (SURVEY C-1/C-2)
             if (!(W - 1 >= max(lo, 0) && W - 1 <= hi)) {
                 const int slot = atomicAdd(&k.rcnt[prow + W - 1], 1);
                 if (slot < RLCAP) k.rlist[(prow + W - 1) * RLCAP + slot] = id;

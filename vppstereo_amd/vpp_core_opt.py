@@ -1,6 +1,7 @@
 """Drop-in for the reference's Cython module ``vpp_core_opt`` (vpp_core/vpp_core_opt.pyx):
 same function names, argument order and in-place semantics, executed by the HIP library.
 
+    get_seed()                                        .pyx:23-28   wall-clock seconds (float)
     init_rand(seed)                                   .pyx:33-35
     virtual_projection_scan_rnd(l, r, g, ...)         .pyx:53-54   -> number of hints
     virtual_projection_scan_max_dist(l, r, g, ...)    .pyx:133-134 -> number of hints
@@ -15,6 +16,12 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+
+
+def get_seed():
+    """Wall-clock seed, CLOCK_REALTIME seconds as a float (.pyx:23-28)."""
+    import time
+    return time.clock_gettime(time.CLOCK_REALTIME)
 
 
 def init_rand(_seed=0):
