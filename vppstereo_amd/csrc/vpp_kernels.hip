@@ -682,6 +682,64 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
     return true;
 }
 
+// Two thread mappings compute the same per-pixel chain replay.  Sparse frames (hints * patch
+// area <= pixels): one thread per (hint, patch pixel); the thread of the LAST hint (scan order)
+// in the pixel's window owns the pixel and replays every hint of the window.  Dense frames: one
+// thread per pixel.  The choice is per frame, from the hint count left by rowscan_kernel.
+__device__ __forceinline__ bool l_pixel_driven(const VppK &k, int f, int patch_area)
+{
+    return k.frame_tot[2 * f + 1] * (unsigned long long)patch_area > (unsigned long long)k.H * k.W;
+}
+
+template <int NWIN>
+__global__ void __launch_bounds__(64) apply_l_hint_kernel(VppK k)
+{
+    constexpr int n = (NWIN - 1) / 2, NP = NWIN * NWIN;
+    const int y = blockIdx.x, f = blockIdx.y;
+    const int W = k.W, H = k.H;
+    if (l_pixel_driven(k, f, NP)) return;
+    const size_t rowoff = ((size_t)f * H + y) * W;
+    const int cnt = k.row_count[(size_t)f * H + y];
+    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+    const float *gf = k.g + (size_t)f * H * W;
+    for (int t = threadIdx.x; t < cnt * NP; t += 64) {
+        const int i = t / NP, p = t % NP;
+        const int a = p / NWIN, b = p % NWIN;
+        const int hx = k.rec[rowoff + i].x;
+        const int yp = y + a - n, xp = hx + b - n; // the patch pixel this thread stands for
+        if (yp < 0 || yp > H - 1 || xp < 0 || xp > W - 1) continue;
+        unsigned long long mask = 0;
+        float gw[NP];
+#pragma unroll
+        for (int wa = 0; wa < NWIN; wa++)
+#pragma unroll
+            for (int wb = 0; wb < NWIN; wb++) {
+                const int yy = yp - n + wa;
+                const int xx = k.direction ? xp - n + wb : xp + n - wb; // bit order = scan order (pyx:78,129)
+                const bool in = yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
+                gw[wa * NWIN + wb] = in ? gf[(size_t)yy * W + xx] : 0.f;
+            }
+#pragma unroll
+        for (int q = 0; q < NP; q++) mask |= (gw[q] > 0) ? (1ull << q) : 0ull;
+        // this hint's own bit in that window; a later bit means another hint's thread owns the pixel
+        const int my_bit = (2 * n - a) * NWIN + (k.direction ? 2 * n - b : b);
+        if ((mask >> my_bit) >> 1) continue;
+        u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
+        u8 L[4] = {0, 0, 0, 0};
+        for (int j = 0; j < k.C; j++) L[j] = px[j];
+        bool touched = false;
+        while (mask) {
+            const int q = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int yy = yp - n + q / NWIN;
+            const int xx = k.direction ? xp - n + q % NWIN : xp + n - q % NWIN;
+            touched |= l_apply_hint(k, f, yp, xp, yy, xx, gf[(size_t)yy * W + xx], L, rnd_f);
+        }
+        if (touched)
+            for (int j = 0; j < k.C; j++) px[j] = L[j];
+    }
+}
+
 // NWIN = 2n+1 for n <= 3 (window fits a 64-bit mask): phase A loads the whole window of hint
 // values with independent loads and records, in scan order, which positions hold a hint;
 // phase B visits only those (a wave iterates max-count times, not (2n+1)^2 times).
@@ -700,6 +758,7 @@ __global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
     u8 L[4] = {0, 0, 0, 0};
     if constexpr (NWIN > 0) {
         constexpr int n = (NWIN - 1) / 2;
+        if (!l_pixel_driven(k, f, NWIN * NWIN)) return; // sparse frame: apply_l_hint_kernel does it
         unsigned long long mask = 0;
         float gw[NWIN * NWIN];
 #pragma unroll
@@ -1038,6 +1097,14 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     if ((rc = ws_get(ctx, WS_RLIST, npx * RLCAP, &k.rlist))) return rc;
     VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
     rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
+    VPPX_CHECK_LAUNCH();
+    switch (k.n) { // sparse frames (each frame picks one of the two mappings on the device)
+    case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
+    case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
+    case 2: apply_l_hint_kernel<5><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
+    case 3: apply_l_hint_kernel<7><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
+    default: break;
+    }
     VPPX_CHECK_LAUNCH();
     switch (k.n) {
     case 0: apply_l_kernel<1><<<grid, 256, 0, ctx->stream>>>(k); break;
