@@ -592,38 +592,96 @@ __global__ void __launch_bounds__(256) rlist_kernel(VppK k)
 // pixels are not even read.  A list that overflowed (> RLCAP hints on one pixel: very dense
 // hints) falls back to scanning the hint rows.
 // ---------------------------------------------------------------------------------------
+// replay of one R pixel from its (complete, n <= RLCAP) list
+__device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int q, size_t pidx, int n)
+{
+    const int H = k.H;
+    u8 *px = k.r + pidx * k.C;
+    u8 R[4] = {0, 0, 0, 0};
+    for (int j = 0; j < k.C; j++) R[j] = px[j];
+    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+    u32 ids[RLCAP];
+#pragma unroll
+    for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? k.rlist[pidx * RLCAP + i] : 0xFFFFFFFFu;
+    // scan order = ascending (row, idx in row): sorting network for 8 keys
+#define CS(a, b) { const u32 lo_ = min(ids[a], ids[b]), hi_ = max(ids[a], ids[b]); ids[a] = lo_; ids[b] = hi_; }
+    CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
+    CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
+#undef CS
+#pragma unroll
+    for (int i = 0; i < RLCAP; i++) {
+        if (i < n) {
+            const int yy = (int)(ids[i] >> 16), hi = (int)(ids[i] & 0xFFFFu);
+            r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], 0x7FFFFFFF);
+        }
+    }
+    for (int j = 0; j < k.C; j++) px[j] = R[j];
+}
+
+// Like the L side, two thread mappings: sparse frames walk the (hint, patch row, target column)
+// triples of rlist_kernel again and the thread of the LAST hint (scan order) in the pixel's list
+// replays it; dense frames -- and pixels whose list overflowed -- use one thread per pixel.
+__device__ __forceinline__ bool r_pixel_driven(const VppK &k, int f)
+{
+    const unsigned long long per_hint = (unsigned long long)(2 * k.n + 1) * (2 * k.n + 2);
+    return k.frame_tot[2 * f + 1] * per_hint > (unsigned long long)k.H * k.W;
+}
+
+__global__ void __launch_bounds__(64) apply_r_hint_kernel(VppK k)
+{
+    const int y = blockIdx.x, f = blockIdx.y;
+    const int W = k.W, H = k.H;
+    if (r_pixel_driven(k, f)) return;
+    const size_t rowoff = ((size_t)f * H + y) * W;
+    const int cnt = k.row_count[(size_t)f * H + y];
+    const int span = 2 * k.n + 1, tw = 2 * k.n + 2;
+    for (int t = threadIdx.x; t < cnt * span * tw; t += 64) {
+        const int i = t / (span * tw), rem = t % (span * tw);
+        const int yw = rem / tw - k.n, tq = rem % tw;
+        const int yp = y + yw;
+        if (yp < 0 || yp > H - 1) continue;
+        const u32 rg = k.rng[rowoff + i];
+        const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
+        const size_t prow = ((size_t)f * H + yp) * W;
+        const u32 id = ((u32)y << 16) | (u32)i;
+        // the (up to two) pixels this thread appended to in rlist_kernel
+        int qs[2] = {-1, -1};
+        const int q0 = lo + tq;
+        if (q0 >= 0 && q0 <= hi && q0 <= W - 1) qs[0] = q0;
+        if (tq == 0 && lo < 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi)) qs[1] = W - 1;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int q = qs[c];
+            if (q < 0) continue;
+            const size_t pidx = prow + q;
+            const int n = k.rcnt[pidx];
+            if (n > RLCAP) continue; // overflowed list: apply_r_kernel scans the rows
+            u32 mx = 0;
+            for (int e = 0; e < n; e++) mx = max(mx, k.rlist[pidx * RLCAP + e]);
+            if (mx != id) continue;  // a later hint's thread owns the pixel
+            r_replay_list(k, f, yp, q, pidx, n);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int yp = blockIdx.y, f = blockIdx.z;
     const int W = k.W, H = k.H;
     if (q >= W) return;
+    const bool all = r_pixel_driven(k, f);
     const size_t pidx = ((size_t)f * H + yp) * W + q;
     const int n = k.rcnt[pidx];
     if (n == 0) return;
+    if (n <= RLCAP) {
+        if (all) r_replay_list(k, f, yp, q, pidx, n);
+        return;
+    }
     u8 *px = k.r + pidx * k.C;
     u8 R[4] = {0, 0, 0, 0};
     for (int j = 0; j < k.C; j++) R[j] = px[j];
-    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
-    if (n <= RLCAP) {
-        u32 ids[RLCAP];
-#pragma unroll
-        for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? k.rlist[pidx * RLCAP + i] : 0xFFFFFFFFu;
-        // scan order = ascending (row, idx in row): sorting network for 8 keys
-#define CS(a, b) { const u32 lo_ = min(ids[a], ids[b]), hi_ = max(ids[a], ids[b]); ids[a] = lo_; ids[b] = hi_; }
-        CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
-        CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
-#undef CS
-#pragma unroll
-        for (int i = 0; i < RLCAP; i++) {
-            if (i < n) {
-                const int yy = (int)(ids[i] >> 16), hi = (int)(ids[i] & 0xFFFFu);
-                r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], 0x7FFFFFFF);
-            }
-        }
-    } else {
-        r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
-    }
+    r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
     for (int j = 0; j < k.C; j++) px[j] = R[j];
 }
 
@@ -1113,6 +1171,8 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     case 3: apply_l_kernel<7><<<grid, 256, 0, ctx->stream>>>(k); break;
     default: apply_l_kernel<0><<<grid, 256, 0, ctx->stream>>>(k); break;
     }
+    VPPX_CHECK_LAUNCH();
+    apply_r_hint_kernel<<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
     apply_r_kernel<<<grid, 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
