@@ -1291,10 +1291,29 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    // one block per CU is resident (LDS); aim at ~4 equal blocks per CU
-    static int target = getenv("VPPX_SUM_BLOCKS") ? atoi(getenv("VPPX_SUM_BLOCKS")) : 1024;
-    int chunks = (target + B - 1) / B;
-    chunks = chunks < 1 ? 1 : (chunks > Hp ? Hp : chunks);
+    // one block per CU is resident (LDS): pick the rows-per-block split with the shortest makespan,
+    // (waves of blocks over the CUs) x (rounds per block incl. its fill/drain rounds)
+    static int forced = getenv("VPPX_SUM_BLOCKS") ? atoi(getenv("VPPX_SUM_BLOCKS")) : 0;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        VPPX_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int ntiles = (Wp + T - 1) / T;
+    int chunks = 1;
+    if (forced > 0) {
+        chunks = (forced + B - 1) / B;
+        chunks = chunks > Hp ? Hp : chunks;
+    } else {
+        long best = -1;
+        for (int c = 1; c <= Hp && c <= 256; c++) {
+            const long rows = (Hp + c - 1) / c;
+            const long nb = (long)((Hp + rows - 1) / rows) * B;
+            const long cost = ((nb + ncu - 1) / ncu) * (rows * ntiles + NR + 2);
+            if (best < 0 || cost < best) { best = cost; chunks = c; }
+        }
+    }
     const int rpb = (Hp + chunks - 1) / chunks;
     chunks = (Hp + rpb - 1) / rpb;
     sum_wta_lr_kernel<DPL, IT, NV, T, SPARE><<<dim3(chunks, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
