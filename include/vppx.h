@@ -201,6 +201,10 @@ int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float
  * context's stream with hipEvents around the kernel only; returns average ms per launch
  * in *ms_out.  Operates on the workspace state left by the last vppx_rsgm_dev call. */
 int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out);
+/* Average duration (ms) of the aggregation kernel over the last `last_n` launches the pipeline made
+ * on this context, from hipEvent pairs recorded around every launch on its launch stream (ring of
+ * 64).  Call after synchronising.  last_n <= 0 resets the launch counter.  n_used may be NULL. */
+int vppx_agg_kernel_ms(vppx_ctx *ctx, int last_n, float *avg_ms, int *n_used);
 /* Frames per launch that vppx_time_aggregate re-runs: vppx_vpp_rsgm_dev splits a batch over
  * internal sub-streams, and the helper times the launches of one part. */
 int vppx_time_aggregate_frames(vppx_ctx *ctx);

@@ -27,7 +27,7 @@ EXPORTS = [
     "vppx_rand_stream", "vppx_virtual_projection_scan_rnd", "vppx_virtual_projection_scan_max_dist", "vppx_vpp_host",
     "vppx_vpp_dev", "vppx_vpp_last_draws", "vppx_census5x5", "vppx_cost_census5x5_xyd", "vppx_aggregate", "vppx_match_wta",
     "vppx_match_wta_right", "vppx_subpixel_refine", "vppx_median3x3", "vppx_rsgm_host", "vppx_rsgm_dev",
-    "vppx_vpp_rsgm_dev", "vppx_u8_to_nchw_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_time_aggregate", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert",
+    "vppx_vpp_rsgm_dev", "vppx_u8_to_nchw_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_time_aggregate", "vppx_agg_kernel_ms", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert",
     "vppx_enable_stage_timing", "vppx_get_stage_ms", "vppx_stage_name",
 ]
 
@@ -122,6 +122,7 @@ def load():
         lib.vppx_occlusion_heuristic_host.argtypes = [vp, i, i, i, vp, i, i, d, d, d, d, vp]
         lib.vppx_occlusion_heuristic_dev.argtypes = [vp, i, i, i, vp, i, i, d, d, d, d, vp]
         lib.vppx_time_aggregate.argtypes = [vp, i, C.POINTER(C.c_float)]
+        lib.vppx_agg_kernel_ms.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         lib.vppx_time_aggregate_frames.argtypes = [vp]
         lib.vppx_time_aggregate_part.argtypes = [vp, i, i, C.POINTER(C.c_float)]
         lib.vppx_uses_vert.argtypes = [vp]

@@ -150,6 +150,9 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
         if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
     if (ctx->ev_created)
         for (int i = 0; i <= VPPX_MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->agg_ev_created)
+        for (int j = 0; j < 2; j++)
+            for (int i = 0; i < vppx_ctx::AGG_RING; i++) (void)hipEventDestroy(ctx->agg_ev[j][i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -375,7 +378,16 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         nvol = 4;
     } else {
         if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * elem_bytes, &paths))) return rc;
+        if (!ctx->agg_ev_created) {
+            for (int j = 0; j < 2; j++)
+                for (int i = 0; i < vppx_ctx::AGG_RING; i++) VPPX_HIP(hipEventCreate(&ctx->agg_ev[j][i]));
+            ctx->agg_ev_created = true;
+        }
+        const int slot = (int)(ctx->agg_calls % vppx_ctx::AGG_RING);
+        VPPX_HIP(hipEventRecord(ctx->agg_ev[0][slot], ctx->stream));
         if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes, 0xFF))) return rc;
+        VPPX_HIP(hipEventRecord(ctx->agg_ev[1][slot], ctx->stream));
+        ctx->agg_calls++;
         for (int k = 0; k < 8; k++) vols[k] = (const u8 *)paths + (size_t)k * ncell * elem_bytes;
         nvol = 8;
     }
@@ -954,6 +966,30 @@ extern "C" int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, floa
 {
     if (part != 1 && part != 2) { vppx_set_error("part must be 1 or 2"); return VPPX_E_INVALID_ARG; }
     return time_aggregation(ctx, iters, part, ms_out);
+}
+// Average duration of the aggregation kernel over the last `last_n` launches made by the pipeline
+// (or by vppx_time_aggregate) on this context, from the hipEvent pairs recorded around each launch
+// on its own stream.  The caller must have synchronised.  last_n <= 0 resets the launch counter.
+extern "C" int vppx_agg_kernel_ms(vppx_ctx *ctx, int last_n, float *avg_ms, int *n_used)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (ctx->nsub > 1 && ctx->sub[0]) ctx = ctx->sub[0]; // split batch: one part's launches
+    if (last_n <= 0) { ctx->agg_calls = 0; if (n_used) *n_used = 0; if (avg_ms) *avg_ms = 0.f; return 0; }
+    if (!avg_ms) return VPPX_E_INVALID_ARG;
+    long n = ctx->agg_calls < last_n ? ctx->agg_calls : last_n;
+    if (n > vppx_ctx::AGG_RING) n = vppx_ctx::AGG_RING;
+    double tot = 0.0;
+    for (long i = 0; i < n; i++) {
+        const int slot = (int)((ctx->agg_calls - 1 - i) % vppx_ctx::AGG_RING);
+        float t = 0.f;
+        VPPX_HIP(hipEventSynchronize(ctx->agg_ev[1][slot]));
+        VPPX_HIP(hipEventElapsedTime(&t, ctx->agg_ev[0][slot], ctx->agg_ev[1][slot]));
+        tot += t;
+    }
+    *avg_ms = n > 0 ? (float)(tot / (double)n) : 0.f;
+    if (n_used) *n_used = (int)n;
+    return 0;
 }
 // frames per launch that vppx_time_aggregate re-runs (a split batch is timed on one part)
 extern "C" int vppx_time_aggregate_frames(vppx_ctx *ctx)

@@ -115,6 +115,12 @@ struct vppx_ctx {
     int last_B = 0, last_Hp = 0, last_Wp = 0, last_D = 0;
     VppxRsgmParams last_rp;
     bool have_last = false;
+    // hipEvent pairs around the aggregation kernel of the most recent pipeline calls (ring), recorded
+    // on the launch stream: vppx_agg_kernel_ms averages them after the caller's synchronize
+    static const int AGG_RING = 64;
+    hipEvent_t agg_ev[2][AGG_RING];
+    bool agg_ev_created = false;
+    long agg_calls = 0;
     // stage timing
     bool stage_timing = false;
     int n_stages = 0;

@@ -112,6 +112,13 @@ class Engine:
         _lib.check(self.lib.vppx_time_aggregate(self.ctx.handle, int(iters), C.byref(ms)))
         return float(ms.value)
 
+    def agg_kernel_ms(self, last_n):
+        """Average duration of the aggregation kernel over the last `last_n` pipeline launches (hipEvent pairs
+        on the launch stream); `last_n <= 0` resets the counter.  Returns (ms, launches averaged)."""
+        ms, n = C.c_float(0), C.c_int(0)
+        _lib.check(self.lib.vppx_agg_kernel_ms(self.ctx.handle, int(last_n), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def time_aggregate_frames(self):
         return int(self.lib.vppx_time_aggregate_frames(self.ctx.handle))
 
