@@ -190,6 +190,27 @@ int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmPara
 int vppx_u8_to_nchw_dev(vppx_ctx *ctx, int B, int H, int W, int C, int pad_multiple, const uint8_t *src, void *dst,
                         int dst_is_bf16);
 
+/* PSMNet matching volume (models/psmnet/psmnet.py:157-197): fea_l/fea_r float32 [B,C,H4,W4] ->
+ * cost float32 [B,2C,maxdisp/4,H4,W4] (caller-allocated, every element written):
+ *   cost[b,c,i,y,x] = x>=i ? fea_l[b,c,y,x] : 0,  cost[b,C+c,i,y,x] = x>=i ? fea_r[b,c,y,x-i] : 0,
+ * multiplied, when hints != NULL, by (1-v) + v*10*exp(-(i-h)^2 / (2*(1/4)^2)) with h, v the hints
+ * (float32 [B,1,H,W], H/4 == H4, W/4 == W4) and validhints sub-sampled 'nearest' like F.upsample and
+ * h = hints*valid/4 (psmnet.py:172-197).  float32 throughout; exp() is the only inexact step. */
+int vppx_psmnet_cost_volume_dev(vppx_ctx *ctx, const float *fea_l, const float *fea_r, const float *hints,
+                                const float *validhints, int B, int C, int H4, int W4, int H, int W, int maxdisp,
+                                float *cost);
+/* RAFT-Stereo hint modulation of the all-pairs correlation, in place (models/raft_stereo/corr.py:160-178):
+ * corr float32 [B,H4,W2,1,W3] (= einsum(fmap2,fmap3)/sqrt(D), a library GEMM left to the caller);
+ * corr[b,y,x,0,k] *= (1-v) + v*10*exp(-(k-(x*v-h))^2/2).  Rows without a hint are untouched. */
+int vppx_raft_corr_modulate_dev(vppx_ctx *ctx, float *corr, const float *hints, const float *validhints, int B, int H4,
+                                int W2, int W3, int H, int W);
+/* Disparity payload decoders (dataloaders/frame_utils.py): KITTI uint16 PNG samples -> disp = v/256
+ * float32 + valid = disp>0 uint8 (readDispKITTI :66-69, valid may be NULL); PFM payload (after the
+ * text header) -> float32 [H,W(,3)] flipped upside-down, byte-swapped if big-endian (readPFM :34-64).
+ * Inflating the PNG stays with the host's image library. */
+int vppx_kitti_disp_decode_dev(vppx_ctx *ctx, const uint16_t *png_u16, int64_t n, float *disp, uint8_t *valid);
+int vppx_pfm_decode_dev(vppx_ctx *ctx, const uint8_t *raw, int H, int W, int channels, int little_endian, float *out);
+
 /* ---- occlusion heuristic (filter.py:246-292): hints -> g_occ mask ------------------------- */
 int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l,
                                   double g, double th_conf, double th_filter, uint8_t *conf_out);

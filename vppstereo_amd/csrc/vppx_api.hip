@@ -749,6 +749,55 @@ extern "C" int vppx_u8_to_nchw_dev(vppx_ctx *ctx, int B, int H, int W, int C, in
 }
 
 // ---------------------------------------------------------------------------------------
+// hand-off rows: PSMNet volume, RAFT correlation modulation, payload decoders
+// ---------------------------------------------------------------------------------------
+extern "C" int vppx_psmnet_cost_volume_dev(vppx_ctx *ctx, const float *fea_l, const float *fea_r, const float *hints,
+                                           const float *validhints, int B, int C, int H4, int W4, int H, int W,
+                                           int maxdisp, float *cost)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!fea_l || !fea_r || !cost || B <= 0 || C <= 0 || H4 <= 0 || W4 <= 0 || maxdisp < 4 || (hints && !validhints)) {
+        vppx_set_error("vppx_psmnet_cost_volume: bad arguments");
+        return VPPX_E_INVALID_ARG;
+    }
+    return handoff_psmnet_cost_volume(ctx, fea_l, fea_r, hints, validhints, B, C, H4, W4, H, W, maxdisp, cost);
+}
+
+extern "C" int vppx_raft_corr_modulate_dev(vppx_ctx *ctx, float *corr, const float *hints, const float *validhints, int B,
+                                           int H4, int W2, int W3, int H, int W)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!corr || !hints || !validhints || B <= 0 || H4 <= 0 || W2 <= 0 || W3 <= 0) {
+        vppx_set_error("vppx_raft_corr_modulate: bad arguments");
+        return VPPX_E_INVALID_ARG;
+    }
+    return handoff_raft_corr_modulate(ctx, corr, hints, validhints, B, H4, W2, W3, H, W);
+}
+
+extern "C" int vppx_kitti_disp_decode_dev(vppx_ctx *ctx, const uint16_t *png_u16, int64_t n, float *disp, uint8_t *valid)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!png_u16 || !disp || n < 0) { vppx_set_error("vppx_kitti_disp_decode: bad arguments"); return VPPX_E_INVALID_ARG; }
+    if (n == 0) return 0;
+    return handoff_kitti_decode(ctx, png_u16, (size_t)n, disp, valid);
+}
+
+extern "C" int vppx_pfm_decode_dev(vppx_ctx *ctx, const uint8_t *raw, int H, int W, int channels, int little_endian,
+                                   float *out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!raw || !out || H <= 0 || W <= 0 || (channels != 1 && channels != 3) || ((uintptr_t)raw & 3)) {
+        vppx_set_error("vppx_pfm_decode: bad arguments (channels must be 1 or 3, payload 4-byte aligned)");
+        return VPPX_E_INVALID_ARG;
+    }
+    return handoff_pfm_decode(ctx, raw, H, W, channels, little_endian != 0, out);
+}
+
+// ---------------------------------------------------------------------------------------
 // occlusion heuristic
 // ---------------------------------------------------------------------------------------
 extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,

@@ -87,6 +87,8 @@ enum WsSlot {
     WS_OCC_OMAP,
     WS_OCC_CONF,
     WS_NHINTS,
+    WS_HANDOFF_H,    // hints / valid at feature resolution (hand-off kernels)
+    WS_HANDOFF_V,
     WS_NUM
 };
 
@@ -210,6 +212,14 @@ int vpp_launch_bilateral_fill(vppx_ctx *ctx, const VppxVppParams &p, const VppGe
                               float *filled_out);
 int vpp_launch_rand_stream(vppx_ctx *ctx, u32 seed, u64 offset, int64_t n, int32_t *out_dev);
 u64 vpp_draws_upper_bound(const VppxVppParams &p, const VppGeom &g);
+
+// handoff_kernels.hip
+int handoff_psmnet_cost_volume(vppx_ctx *ctx, const float *fl, const float *fr, const float *hints, const float *valid, int B,
+                               int C, int H4, int W4, int H, int W, int maxdisp, float *cost);
+int handoff_raft_corr_modulate(vppx_ctx *ctx, float *corr, const float *hints, const float *valid, int B, int H4, int W2, int W3,
+                               int H, int W);
+int handoff_kitti_decode(vppx_ctx *ctx, const uint16_t *png, size_t n, float *disp, u8 *valid);
+int handoff_pfm_decode(vppx_ctx *ctx, const u8 *raw, int H, int W, int channels, int little, float *out);
 
 // occ_kernels (in vpp_kernels.hip)
 int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,

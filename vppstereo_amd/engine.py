@@ -106,6 +106,87 @@ class Engine:
                                                 int(dtype == torch.bfloat16)))
         return out
 
+    # ---- hand-off rows ----
+    def psmnet_cost_volume(self, fea_l, fea_r, maxdisp, hints=None, validhints=None):
+        """The tensor PSMNet.forward hands to dres0 (models/psmnet/psmnet.py:157-197): concat volume
+        [B,2C,maxdisp//4,H4,W4] from the two feature maps [B,C,H4,W4], times the hint modulation when
+        hints / validhints ([B,1,H,W] float32) are given."""
+        torch = self.torch
+        self._chk(fea_l, torch.float32, 4, "fea_l")
+        self._chk(fea_r, torch.float32, 4, "fea_r")
+        if fea_r.shape != fea_l.shape:
+            raise ValueError("feature maps must have the same shape")
+        B, Cc, H4, W4 = fea_l.shape
+        H = W = 0
+        if hints is not None:
+            self._chk(hints, torch.float32, 4, "hints")
+            self._chk(validhints, torch.float32, 4, "validhints")
+            if hints.shape != validhints.shape or hints.shape[:2] != (B, 1):
+                raise ValueError("hints / validhints must be [B,1,H,W]")
+            H, W = hints.shape[2:]
+        cost = torch.empty((B, 2 * Cc, int(maxdisp) // 4, H4, W4), dtype=torch.float32, device=self.device)
+        self._bind_stream()
+        _lib.check(self.lib.vppx_psmnet_cost_volume_dev(self.ctx.handle, _ptr(fea_l), _ptr(fea_r),
+                                                        _ptr(hints) if hints is not None else None,
+                                                        _ptr(validhints) if hints is not None else None,
+                                                        B, Cc, H4, W4, int(H), int(W), int(maxdisp), _ptr(cost)))
+        return cost
+
+    def raft_corr(self, fmap2, fmap3, hints=None, validhints=None):
+        """CorrBlock1D.corr (models/raft_stereo/corr.py:151-180): all-pairs correlation along the row
+        (a library GEMM through torch) / sqrt(D), then the hint modulation in place on the device."""
+        torch = self.torch
+        self._chk(fmap2, torch.float32, 4, "fmap2")
+        self._chk(fmap3, torch.float32, 4, "fmap3")
+        B, Dc, H4, W2 = fmap2.shape
+        W3 = fmap3.shape[3]
+        corr = torch.einsum('aijk,aijh->ajkh', fmap2, fmap3).reshape(B, H4, W2, 1, W3).contiguous()
+        corr = corr / torch.sqrt(torch.tensor(Dc).float())
+        if hints is not None:
+            self._chk(hints, torch.float32, 4, "hints")
+            self._chk(validhints, torch.float32, 4, "validhints")
+            self._bind_stream()
+            _lib.check(self.lib.vppx_raft_corr_modulate_dev(self.ctx.handle, _ptr(corr), _ptr(hints), _ptr(validhints), B, H4,
+                                                            W2, W3, int(hints.shape[2]), int(hints.shape[3])))
+        return corr
+
+    def raft_corr_modulate_(self, corr, hints, validhints):
+        """In-place hint modulation of an existing correlation volume [B,H4,W2,1,W3] (corr.py:160-178)."""
+        torch = self.torch
+        self._chk(corr, torch.float32, 5, "corr")
+        self._chk(hints, torch.float32, 4, "hints")
+        self._chk(validhints, torch.float32, 4, "validhints")
+        B, H4, W2, _, W3 = corr.shape
+        self._bind_stream()
+        _lib.check(self.lib.vppx_raft_corr_modulate_dev(self.ctx.handle, _ptr(corr), _ptr(hints), _ptr(validhints), B, H4, W2,
+                                                        W3, int(hints.shape[2]), int(hints.shape[3])))
+        return corr
+
+    def kitti_disp_decode(self, png_u16):
+        """uint16 PNG samples (device tensor, int16/uint16 storage) -> (disp float32, valid uint8), same shape
+        (frame_utils.readDispKITTI :66-69)."""
+        torch = self.torch
+        if png_u16.dtype not in (torch.int16, torch.uint16) or not png_u16.is_contiguous() or not png_u16.is_cuda:
+            raise ValueError("png_u16 must be a contiguous 16-bit device tensor")
+        disp = torch.empty(png_u16.shape, dtype=torch.float32, device=self.device)
+        valid = torch.empty(png_u16.shape, dtype=torch.uint8, device=self.device)
+        self._bind_stream()
+        _lib.check(self.lib.vppx_kitti_disp_decode_dev(self.ctx.handle, _ptr(png_u16), png_u16.numel(), _ptr(disp), _ptr(valid)))
+        return disp, valid
+
+    def pfm_decode(self, raw_u8, height, width, channels=1, little_endian=True):
+        """PFM payload bytes (device uint8 tensor, header stripped) -> float32 [H,W] or [H,W,3], flipped
+        upside-down like frame_utils.readPFM (:34-64)."""
+        torch = self.torch
+        self._chk(raw_u8, torch.uint8, 1, "raw")
+        if raw_u8.numel() != height * width * channels * 4:
+            raise ValueError("payload size does not match height*width*channels*4")
+        out = torch.empty((height, width, 3) if channels == 3 else (height, width), dtype=torch.float32, device=self.device)
+        self._bind_stream()
+        _lib.check(self.lib.vppx_pfm_decode_dev(self.ctx.handle, _ptr(raw_u8), int(height), int(width), int(channels),
+                                                int(bool(little_endian)), _ptr(out)))
+        return out
+
     # ---- measurement helpers (bench.py) ----
     def time_aggregate(self, iters=10):
         ms = C.c_float()
