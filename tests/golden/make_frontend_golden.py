@@ -132,5 +132,23 @@ for tag, chans, little in (("g", 1, True), ("c", 3, False)):
     out[f"pfm_{tag}_meta"] = np.array([Hh, Ww, chans, int(little)], np.int64)
     out[f"pfm_{tag}_dec"] = np.ascontiguousarray(dec).astype(np.float32)
 
+# ---- harness rows a20: losses.py:5-24 ----------------------------------------------------------
+spec = importlib.util.spec_from_file_location("ref_losses", os.path.join(REF, "losses.py"))
+RL = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(RL)
+lh = rng.uniform(0, 190, (2, 1, 13, 17)).astype(np.float32)
+lv = (rng.random((2, 1, 13, 17)) < 0.7).astype(np.float32)
+lh[0, 0, 0, 0], lv[0, 0, 0, 0] = np.inf, 1.0       # dropped or not, never NaN
+torch.manual_seed(123)
+nh, nv = RL.sample_hints(torch.from_numpy(lh.copy()), torch.from_numpy(lv.copy()), 0.4)
+out["loss_hints"], out["loss_valid"] = lh, lv
+out["loss_new_hints"], out["loss_new_valid"] = nh.numpy(), nv.numpy()
+md, mg = rng.uniform(0, 60, (19, 23)).astype(np.float32), rng.uniform(0, 60, (19, 23)).astype(np.float32)
+mv = (rng.random((19, 23)) < 0.6).astype(np.float32)
+m = RL.guided_metrics(md.copy(), mg.copy(), mv.copy())
+out["met_disp"], out["met_gt"], out["met_valid"] = md, mg, mv
+for k, v in m.items():
+    out["met_" + k.replace(" ", "_").replace(".", "p")] = np.asarray(v)
+
 np.savez_compressed(os.path.join(HERE, "frontend_cases.npz"), **out)
 print("wrote", len(out), "arrays")

@@ -45,3 +45,17 @@ def test_decoders_match_reference():
         H, W, ch, little = (int(x) for x in G[f"pfm_{tag}_meta"])
         got = FO.pfm_decode(G[f"pfm_{tag}_raw"].tobytes(), H, W, ch, bool(little))
         assert np.array_equal(got, G[f"pfm_{tag}_dec"])
+
+
+def test_losses_match_reference():
+    """vppstereo_amd.losses (rows a20) against losses.py:5-24 run by the golden script."""
+    import torch
+    from vppstereo_amd import losses
+    torch.manual_seed(123)
+    nh, nv = losses.sample_hints(torch.from_numpy(G["loss_hints"].copy()), torch.from_numpy(G["loss_valid"].copy()), 0.4)
+    assert np.array_equal(nv.numpy(), G["loss_new_valid"])
+    assert np.array_equal(nh.numpy(), G["loss_new_hints"], equal_nan=True)
+    m = losses.guided_metrics(G["met_disp"].copy(), G["met_gt"].copy(), G["met_valid"].copy())
+    for k, v in m.items():
+        ref = G["met_" + k.replace(" ", "_").replace(".", "p")]
+        assert np.array_equal(np.asarray(v), ref), k

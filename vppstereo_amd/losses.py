@@ -5,11 +5,15 @@ import numpy as np
 
 
 def sample_hints(hints, validhints, probability=0.20):
+    """Keep each valid hint with the given probability (losses.py:5-10): one torch.rand_like draw per
+    element of validhints (so the RNG stream is consumed like the reference does), dropped hints are
+    exactly 0 even where the input held inf / NaN.  Works on CPU and device tensors alike."""
     import torch
-    new_validhints = (validhints * (torch.rand_like(validhints, dtype=torch.float32) < probability)).float()
-    new_hints = hints * new_validhints
-    new_hints[new_validhints == 0] = 0
-    return new_hints, new_validhints
+    keep = torch.rand_like(validhints, dtype=torch.float32) < probability
+    sampled_valid = (validhints * keep).float()
+    product = hints * sampled_valid
+    sampled_hints = torch.where(sampled_valid == 0, torch.zeros_like(product), product)
+    return sampled_hints, sampled_valid
 
 
 def guided_metrics(disp, gt, valid):
