@@ -578,7 +578,9 @@ __global__ void __launch_bounds__(256) rlist_kernel(VppK k)
             const int slot = atomicAdd(&k.rcnt[prow + q], 1);
             if (slot < RLCAP) k.rlist[(prow + q) * RLCAP + slot] = id;
         }
-        if (tq == 0 && lo < 0) { // Python-style wraparound target: column W-1 (SURVEY C-1/C-2)
+        // Python-style wraparound target, column W-1 (SURVEY C-1/C-2): only the un-interpolated write
+        // r[.., xd+xw] with xd = xd0-1 and xd0+xw == 0 can index -1 (pyx:113,121), i.e. lo < 0 <= hi
+        if (tq == 0 && !k.interp && lo < 0 && hi >= 0) {
             if (!(W - 1 >= max(lo, 0) && W - 1 <= hi)) {
                 const int slot = atomicAdd(&k.rcnt[prow + W - 1], 1);
                 if (slot < RLCAP) k.rlist[(prow + W - 1) * RLCAP + slot] = id;
@@ -592,17 +594,16 @@ __global__ void __launch_bounds__(256) rlist_kernel(VppK k)
 // pixels are not even read.  A list that overflowed (> RLCAP hints on one pixel: very dense
 // hints) falls back to scanning the hint rows.
 // ---------------------------------------------------------------------------------------
-// replay of one R pixel from its (complete, n <= RLCAP) list
-__device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int q, size_t pidx, int n)
+// replay of one R pixel from its (complete, n <= RLCAP) list; ids[] holds the list (entries >= n ignored)
+__device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int q, size_t pidx, int n, u32 (&ids)[RLCAP])
 {
     const int H = k.H;
     u8 *px = k.r + pidx * k.C;
     u8 R[4] = {0, 0, 0, 0};
     for (int j = 0; j < k.C; j++) R[j] = px[j];
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
-    u32 ids[RLCAP];
 #pragma unroll
-    for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? k.rlist[pidx * RLCAP + i] : 0xFFFFFFFFu;
+    for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? ids[i] : 0xFFFFFFFFu;
     // scan order = ascending (row, idx in row): sorting network for 8 keys
 #define CS(a, b) { const u32 lo_ = min(ids[a], ids[b]), hi_ = max(ids[a], ids[b]); ids[a] = lo_; ids[b] = hi_; }
     CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
@@ -617,10 +618,19 @@ __device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int 
     }
     for (int j = 0; j < k.C; j++) px[j] = R[j];
 }
+// the whole list record of a pixel: two 16-byte loads (RLCAP = 8 entries of 4 bytes, 32-byte aligned)
+__device__ __forceinline__ void r_load_list(const VppK &k, size_t pidx, u32 (&ids)[RLCAP])
+{
+    static_assert(RLCAP == 8, "list record = 2 x uint4");
+    const uint4 a = ((const uint4 *)k.rlist)[pidx * 2], b = ((const uint4 *)k.rlist)[pidx * 2 + 1];
+    ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w;
+    ids[4] = b.x; ids[5] = b.y; ids[6] = b.z; ids[7] = b.w;
+}
 
 // Like the L side, two thread mappings: sparse frames walk the (hint, patch row, target column)
 // triples of rlist_kernel again and the thread of the LAST hint (scan order) in the pixel's list
-// replays it; dense frames -- and pixels whose list overflowed -- use one thread per pixel.
+// replays it (for an overflowed list: the thread of the FIRST listed hint scans the hint rows);
+// dense frames use one thread per pixel.
 __device__ __forceinline__ bool r_pixel_driven(const VppK &k, int f)
 {
     const unsigned long long per_hint = (unsigned long long)(2 * k.n + 1) * (2 * k.n + 2);
@@ -648,18 +658,30 @@ __global__ void __launch_bounds__(64) apply_r_hint_kernel(VppK k)
         int qs[2] = {-1, -1};
         const int q0 = lo + tq;
         if (q0 >= 0 && q0 <= hi && q0 <= W - 1) qs[0] = q0;
-        if (tq == 0 && lo < 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi)) qs[1] = W - 1;
+        if (tq == 0 && !k.interp && lo < 0 && hi >= 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi)) qs[1] = W - 1;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const int q = qs[c];
             if (q < 0) continue;
             const size_t pidx = prow + q;
             const int n = k.rcnt[pidx];
-            if (n > RLCAP) continue; // overflowed list: apply_r_kernel scans the rows
+            u32 ids[RLCAP];
+            r_load_list(k, pidx, ids); // independent of n: both loads are in flight together
+            if (n > RLCAP) { // overflowed list (typically column W-1, the wraparound target of every hint near
+                             // the left border): the thread of the first listed hint scans the hint rows instead
+                if (id != ids[0]) continue;
+                u8 *px = k.r + pidx * k.C;
+                u8 R[4] = {0, 0, 0, 0};
+                for (int j = 0; j < k.C; j++) R[j] = px[j];
+                r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
+                for (int j = 0; j < k.C; j++) px[j] = R[j];
+                continue;
+            }
             u32 mx = 0;
-            for (int e = 0; e < n; e++) mx = max(mx, k.rlist[pidx * RLCAP + e]);
+#pragma unroll
+            for (int e = 0; e < RLCAP; e++) mx = e < n ? max(mx, ids[e]) : mx;
             if (mx != id) continue;  // a later hint's thread owns the pixel
-            r_replay_list(k, f, yp, q, pidx, n);
+            r_replay_list(k, f, yp, q, pidx, n, ids);
         }
     }
 }
@@ -670,12 +692,14 @@ __global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
     const int yp = blockIdx.y, f = blockIdx.z;
     const int W = k.W, H = k.H;
     if (q >= W) return;
-    const bool all = r_pixel_driven(k, f);
+    if (!r_pixel_driven(k, f)) return; // sparse frame: apply_r_hint_kernel did everything
     const size_t pidx = ((size_t)f * H + yp) * W + q;
     const int n = k.rcnt[pidx];
     if (n == 0) return;
     if (n <= RLCAP) {
-        if (all) r_replay_list(k, f, yp, q, pidx, n);
+        u32 ids[RLCAP];
+        r_load_list(k, pidx, ids);
+        r_replay_list(k, f, yp, q, pidx, n, ids);
         return;
     }
     u8 *px = k.r + pidx * k.C;
