@@ -250,3 +250,41 @@ def test_batched_vpp_is_sharding_independent():
         n = oracle.virtual_projection_scan_rnd(a0, b0, b["hints"][f], 64, 40, 3, False, 3, 1, 0.4, 0.0,
                                                np.zeros((40, 64), np.uint8), False, True)
         assert n == nh[f] and np.array_equal(a0, l_all[f]) and np.array_equal(b0, r_all[f])
+
+
+@pytest.mark.parametrize("kw", [dict(wsize=3, interpolate=1), dict(wsize=3, interpolate=0, discard_occluded=0),
+                                dict(wsize=5, interpolate=1, direction=0), dict(wsize=7, interpolate=0, uniform_color=1),
+                                dict(wsize=1, interpolate=1)])
+def test_mixed_density_batch_uses_both_thread_mappings(kw):
+    """One batch whose frames fall on both sides of the per-frame sparse/dense switch of the L and R
+    kernels (hints x patch area vs pixels), with occluded hints, hints hugging the left border
+    (targets < 0, the -1 wraparound of the un-interpolated write) and large disparities."""
+    from vppstereo_amd import _lib
+    lib, ctx = _lib.load(), _lib.default_context()
+    H, W, C3 = 36, 90, 3
+    dens = [0.0, 0.004, 0.03, 0.08, 0.1, 0.12, 0.3, 1.0]
+    B = len(dens)
+    rng = np.random.default_rng(99)
+    l = rng.integers(0, 256, (B, H, W, C3), dtype=np.uint8)
+    r = rng.integers(0, 256, (B, H, W, C3), dtype=np.uint8)
+    g = np.zeros((B, H, W), np.float32)
+    occ = np.zeros((B, H, W), np.uint8)
+    for f, p in enumerate(dens):
+        m = rng.random((H, W)) < p
+        g[f][m] = rng.uniform(0.2, 40.0, int(m.sum())).astype(np.float32)
+        g[f][:, :3][m[:, :3]] = rng.choice(np.array([0.5, 1.5, 2.49, 2.5, 3.0], np.float32), int(m[:, :3].sum()))
+        occ[f] = (rng.random((H, W)) < 0.3) & m
+    lg, rg = l.copy(), r.copy()
+    p = _lib.vpp_params(seed=321, c_occ=0.15, **kw)
+    nh = (C.c_int64 * B)()
+    _lib.check(lib.vppx_vpp_host(ctx.handle, C.byref(p), B, H, W, C3, _lib.np_ptr(lg), _lib.np_ptr(rg), _lib.np_ptr(g),
+                                 _lib.np_ptr(occ), None, nh))
+    for f in range(B):
+        a0, b0 = l[f].copy(), r[f].copy()
+        oracle.init_rand(321 + f)
+        n = oracle.virtual_projection_scan_rnd(a0, b0, g[f], W, H, C3, bool(kw.get("uniform_color", 0)), kw["wsize"],
+                                               kw.get("direction", 1), 0.4, 0.15, occ[f],
+                                               bool(kw.get("discard_occluded", 0)), bool(kw["interpolate"]))
+        assert n == nh[f], (f, kw)
+        assert np.array_equal(a0, lg[f]), (f, dens[f], kw)
+        assert np.array_equal(b0, rg[f]), (f, dens[f], kw)
