@@ -139,21 +139,38 @@ def main():
     left = torch.from_numpy(np.ascontiguousarray(base["left"][idx])).to(dev)
     right = torch.from_numpy(np.ascontiguousarray(base["right"][idx])).to(dev)
     hints = torch.from_numpy(np.ascontiguousarray(base["hints"][idx])).to(dev)
-    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    outs = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+    out = outs[0]
     seed0 = vdist.frame_seed(1, lo)
+    pending = [None, None]  # gathers in flight, one per output buffer
+    nstep = [0]
 
-    def local_step():
-        eng.vpp_rsgm(left, right, hints, out=out, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1))
-        return out
+    def local_step(buf=None):
+        buf = out if buf is None else buf
+        eng.vpp_rsgm(left, right, hints, out=buf, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1))
+        return buf
 
     def step():
-        local_step()
+        # the gather of step k (to rank 0, asynchronous) overlaps the kernels of step k+1, which write the
+        # other output buffer; a buffer is reused only after its previous gather has completed
+        k = nstep[0] % 2
+        nstep[0] += 1
+        if pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
+        local_step(outs[k])
         if world > 1 and not args.no_gather:
-            return vdist.gather_disparities(out, n_total, dst=0)  # collective: every rank calls step() equally often
-        return out
+            pending[k] = vdist.gather_disparities_async(outs[k], n_total, dst=0)  # every rank calls step() equally often
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -162,6 +179,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()  # the last gathers complete inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

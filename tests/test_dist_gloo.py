@@ -30,10 +30,15 @@ def _worker(rank, ws, port, n_frames, q):
         local = torch.stack([torch.full((3, 5), float(vdist.frame_seed(100, f))) for f in range(lo, hi)]) \
             if hi > lo else torch.zeros((0, 3, 5))
         full = vdist.gather_disparities(local, n_frames, dst=0)
+        # two overlapping asynchronous gathers (what bench.py keeps in flight), completed out of order
+        h1 = vdist.gather_disparities_async(local + 1.0, n_frames, dst=0)
+        h2 = vdist.gather_disparities_async(local + 2.0, n_frames, dst=0)
+        r2, r1 = h2.result(), h1.result()
         if rank == 0:
+            assert torch.equal(r1, full + 1.0) and torch.equal(r2, full + 2.0)
             q.put(full.numpy())
         else:
-            assert full is None
+            assert full is None and r1 is None and r2 is None
     finally:
         tdist.destroy_process_group()
 
