@@ -16,7 +16,7 @@ sys.path.insert(0, %r)
 import oracle, synth
 from vppstereo_amd.engine import Engine
 eng = Engine()
-for (B, H, W, D) in ((4, 50, 150, 192), (8, 40, 96, 64), (2, 70, 81, 128)):
+for (B, H, W, D) in ((1, 24, 300, 256), (4, 50, 150, 192), (8, 40, 96, 64), (2, 70, 81, 128)):
     b = synth.make_batch(B, H, W, D, 0.05, seed=B * H)
     dev = eng.device
     lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev); rv = torch.empty_like(lv)
@@ -33,7 +33,7 @@ print("VARIANT_OK", eng.uses_vert())
 """ % ROOT
 
 
-@pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_GW="16"), dict(VPPX_GW="4"), dict(VPPX_SUBSTREAMS="2"),
+@pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_GW="16"), dict(VPPX_GW="4"), dict(VPPX_GW="8"), dict(VPPX_SUBSTREAMS="2"),
                                  dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2")])
 def test_variant_matches_oracle(env):
     e = dict(os.environ)

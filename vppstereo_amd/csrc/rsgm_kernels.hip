@@ -728,17 +728,25 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
     // (min reduction, P2 lookup, addressing) over more disparities
     static int gw_override = -1;
     if (gw_override < 0) {
-        const char *e = getenv("VPPX_GW"); // experiment knob: lanes per pixel for D = 192
+        const char *e = getenv("VPPX_GW"); // experiment knob: lanes per pixel (other layouts per D range)
         gw_override = e ? atoi(e) : 0;
     }
-    if (D <= 64) return launch_paths_t<4, 16>(ctx, a, B, from_dsi, elem_bytes);
-    if (D <= 128) return launch_paths_t<4, 32>(ctx, a, B, from_dsi, elem_bytes);
+    if (D <= 64) {
+        if (gw_override == 8) return launch_paths_t<8, 8>(ctx, a, B, from_dsi, elem_bytes);
+        return launch_paths_t<4, 16>(ctx, a, B, from_dsi, elem_bytes);
+    }
+    // 32 disparities per lane need ~150 VGPRs (3 waves/SIMD) and run 1.7-1.8x slower than 16 per lane
+    if (D <= 128) {
+        if (gw_override == 4) return launch_paths_t<4, 32>(ctx, a, B, from_dsi, elem_bytes);
+        return launch_paths_t<8, 16>(ctx, a, B, from_dsi, elem_bytes);
+    }
     if (D <= 192) {
         if (gw_override == 16) return launch_paths_t<16, 12>(ctx, a, B, from_dsi, elem_bytes);
         if (gw_override == 4) return launch_paths_t<4, 48>(ctx, a, B, from_dsi, elem_bytes);
         return launch_paths_t<8, 24>(ctx, a, B, from_dsi, elem_bytes);
     }
-    return launch_paths_t<8, 32>(ctx, a, B, from_dsi, elem_bytes);
+    if (gw_override == 8) return launch_paths_t<8, 32>(ctx, a, B, from_dsi, elem_bytes);
+    return launch_paths_t<16, 16>(ctx, a, B, from_dsi, elem_bytes);
 }
 
 // ---------------------------------------------------------------------------------------
