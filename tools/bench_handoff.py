@@ -71,6 +71,20 @@ def main():
     ms = timeit(lambda: eng.kitti_disp_decode(png))
     nb = png.numel() * (2 + 4 + 1)
     out["kitti_disp_decode"] = {"ms": round(ms, 4), "GBps": round(nb / ms / 1e6, 1), "frames": 64}
+    # cfg 4: VPP only -> network tensors, device resident (17 B/pixel: latency bound)
+    import synth
+    for Bv in (1, 32):
+        b = synth.make_batch(min(Bv, 4), 540, 960, 192, 0.03, seed=1234)
+        idx = [i % min(Bv, 4) for i in range(Bv)]
+        lt = torch.from_numpy(np.ascontiguousarray(b["left"][idx])).to(dev)
+        rt = torch.from_numpy(np.ascontiguousarray(b["right"][idx])).to(dev)
+        ht = torch.from_numpy(np.ascontiguousarray(b["hints"][idx])).to(dev)
+
+        def vpp_to_net():
+            lv, rv = eng.vpp(lt, rt, ht, seed=1)
+            return eng.to_network_input(lv, torch.bfloat16), eng.to_network_input(rv, torch.bfloat16)
+        ms = timeit(vpp_to_net)
+        out[f"vpp_to_bf16_nchw_B{Bv}"] = {"ms": round(ms, 4), "us_per_frame": round(ms * 1e3 / Bv, 1)}
     out["device"] = eng.ctx.device_name
     print(json.dumps(out))
 
