@@ -168,6 +168,10 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
+    if world > 1 and not args.no_gather:
+        # RCCL creates its send/recv channels on first use: do that outside the timed region even with --warmup 0
+        vdist.gather_disparities_async(outs[0], n_total, dst=0).wait()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
