@@ -172,13 +172,20 @@ __device__ __forceinline__ int reflect_idx(int i, int n)
     return i;
 }
 
-__global__ void __launch_bounds__(256) pad_gray_kernel(const u8 *__restrict__ img, u8 *__restrict__ gray, int H, int W,
-                                                       int C, int Hp, int Wp, int pad_t, int pad_l)
+struct ImgSet { // up to three same-shaped inputs / outputs handled by one launch (blockIdx.z = set * B + frame)
+    const void *src[3];
+    void *dst[3];
+};
+
+__global__ void __launch_bounds__(256) pad_gray_kernel(ImgSet io, int B, int H, int W, int C, int Hp, int Wp, int pad_t,
+                                                       int pad_l)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    const int f = blockIdx.z;
+    const int set = blockIdx.z / B, f = blockIdx.z % B;
     if (x >= Wp) return;
+    const u8 *img = (const u8 *)(set == 0 ? io.src[0] : (set == 1 ? io.src[1] : io.src[2]));
+    u8 *gray = (u8 *)(set == 0 ? io.dst[0] : (set == 1 ? io.dst[1] : io.dst[2]));
     const int sy = reflect_idx(y - pad_t, H), sx = reflect_idx(x - pad_l, W);
     const u8 *s = img + (((size_t)f * H + sy) * W + sx) * C;
     u32 v;
@@ -190,12 +197,19 @@ __global__ void __launch_bounds__(256) pad_gray_kernel(const u8 *__restrict__ im
     gray[((size_t)f * Hp + y) * Wp + x] = (u8)v;
 }
 
-int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gray)
+int rsgm_launch_pad_gray_n(vppx_ctx *ctx, const RsgmGeom &g, int n, const u8 *const *img, u8 *const *gray)
 {
-    dim3 grid((g.Wp + 255) / 256, g.Hp, g.B);
-    pad_gray_kernel<<<grid, 256, 0, ctx->stream>>>(img, gray, g.H, g.W, g.C, g.Hp, g.Wp, g.pad_t, g.pad_l);
+    ImgSet io;
+    for (int i = 0; i < 3; i++) { io.src[i] = i < n ? img[i] : nullptr; io.dst[i] = i < n ? gray[i] : nullptr; }
+    dim3 grid((g.Wp + 255) / 256, g.Hp, g.B * n);
+    pad_gray_kernel<<<grid, 256, 0, ctx->stream>>>(io, g.B, g.H, g.W, g.C, g.Hp, g.Wp, g.pad_t, g.pad_l);
     VPPX_CHECK_LAUNCH();
     return 0;
+}
+
+int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gray)
+{
+    return rsgm_launch_pad_gray_n(ctx, g, 1, &img, &gray);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -237,13 +251,14 @@ int rsgm_launch_to_nchw(vppx_ctx *ctx, int B, int H, int W, int C, int mult, con
 // census 5x5 (call site rsgm.py:25-26).  24 bits, row-major, first neighbour = bit 23,
 // bit = (neighbour < centre); 2-px border = 0.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) census5x5_kernel(const u8 *__restrict__ gray, u32 *__restrict__ out, int Hp, int Wp)
+__global__ void __launch_bounds__(256) census5x5_kernel(ImgSet io, int B, int Hp, int Wp)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    const int f = blockIdx.z;
+    const int set = blockIdx.z / B, f = blockIdx.z % B;
     if (x >= Wp) return;
-    const u8 *g = gray + (size_t)f * Hp * Wp;
+    const u8 *g = (const u8 *)(set == 0 ? io.src[0] : io.src[1]) + (size_t)f * Hp * Wp;
+    u32 *out = (u32 *)(set == 0 ? io.dst[0] : io.dst[1]);
     u32 v = 0;
     if (y >= 2 && y < Hp - 2 && x >= 2 && x < Wp - 2) {
         const u32 c = g[(size_t)y * Wp + x];
@@ -258,12 +273,19 @@ __global__ void __launch_bounds__(256) census5x5_kernel(const u8 *__restrict__ g
     out[((size_t)f * Hp + y) * Wp + x] = v;
 }
 
-int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32 *census)
+int rsgm_launch_census_n(vppx_ctx *ctx, int B, int Hp, int Wp, int n, const u8 *const *gray, u32 *const *census)
 {
-    dim3 grid((Wp + 255) / 256, Hp, B);
-    census5x5_kernel<<<grid, 256, 0, ctx->stream>>>(gray, census, Hp, Wp);
+    ImgSet io;
+    for (int i = 0; i < 3; i++) { io.src[i] = i < n ? gray[i] : nullptr; io.dst[i] = i < n ? census[i] : nullptr; }
+    dim3 grid((Wp + 255) / 256, Hp, B * n);
+    census5x5_kernel<<<grid, 256, 0, ctx->stream>>>(io, B, Hp, Wp);
     VPPX_CHECK_LAUNCH();
     return 0;
+}
+
+int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32 *census)
+{
+    return rsgm_launch_census_n(ctx, B, Hp, Wp, 1, &gray, &census);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1641,6 +1663,75 @@ int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const f
 {
     dim3 grid((Wp + 255) / 256, Hp, B);
     linear_interp_clip_kernel<<<grid, 256, 0, ctx->stream>>>(src, dst, Hp, Wp);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
+// Fused median3x3 -> _linear_interpolate -> clip for the left and the right view (rsgm.py:145-151,
+// 173-179): one block per row; the row's medians go to LDS, the interpolation of every hole pixel
+// reads them from there.  (Same arithmetic as the two stand-alone kernels above, which the stage
+// API keeps using.)
+__global__ void __launch_bounds__(256) median_interp_clip_kernel(ImgSet io, int B, int Hp, int Wp)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_med[]; // [Wp]
+    const int y = blockIdx.x;
+    const int set = blockIdx.y / B, f = blockIdx.y % B;
+    const float *s = (const float *)(set == 0 ? io.src[0] : io.src[1]) + (size_t)f * Hp * Wp;
+    float *dst = (float *)(set == 0 ? io.dst[0] : io.dst[1]) + ((size_t)f * Hp + y) * Wp;
+    for (int x = threadIdx.x; x < Wp; x += 256) {
+        float out;
+        if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
+            out = s[(size_t)y * Wp + x];
+        } else {
+            float v[9];
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) v[(dy + 1) * 3 + dx + 1] = s[(size_t)(y + dy) * Wp + x + dx];
+            cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+            cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+            cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+            cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+            cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+            cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+            cswap(v[4], v[2]);
+            out = v[4];
+        }
+        s_med[x] = out;
+    }
+    __syncthreads();
+    const float *row = s_med;
+    for (int x = threadIdx.x; x < Wp; x += 256) {
+        float v = row[x];
+        if (v <= 0) {
+            int xl = -1, xr = -1;
+            for (int k = 1; k <= 13; k++)
+                if (x - k >= 0 && row[x - k] > 0) { xl = x - k; break; }
+            if (xl >= 0) {
+                for (int k = 1; k <= 14 - (x - xl); k++)
+                    if (x + k < Wp && row[x + k] > 0) { xr = x + k; break; }
+            }
+            if (xl >= 0 && xr >= 0) {
+                const double n_left = (double)row[xl], n_right = (double)row[xr];
+                if (fabs(n_left - n_right) < 3.0) {
+                    const int xt = max(xl + 1, xr - 7);
+                    const int n_leftx = xl - xt, n_rightx = xr - xt;
+                    const double m = __ddiv_rn(n_right - n_left, (double)(n_rightx - n_leftx));
+                    const double q = __dsub_rn(n_left, __dmul_rn(m, (double)n_leftx));
+                    v = (float)__dadd_rn(__dmul_rn(m, (double)(x - xt)), q);
+                }
+            }
+        }
+        dst[x] = (v >= 0) ? v : 0.0f; // np.clip(., 0, None)
+    }
+}
+
+int rsgm_launch_median_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src_l, float *dst_l, const float *src_r,
+                                   float *dst_r)
+{
+    ImgSet io;
+    io.src[0] = src_l; io.dst[0] = dst_l; io.src[1] = src_r; io.dst[1] = dst_r; io.src[2] = nullptr; io.dst[2] = nullptr;
+    median_interp_clip_kernel<<<dim3(Hp, 2 * B), 256, (size_t)Wp * sizeof(float), ctx->stream>>>(io, B, Hp, Wp);
     VPPX_CHECK_LAUNCH();
     return 0;
 }

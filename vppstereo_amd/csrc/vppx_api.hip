@@ -413,13 +413,16 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_CENSUS_L, npp, &cl))) return rc;
     if ((rc = ws_get(ctx, WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
     u32 *cr = cr_raw + 512;
-    if ((rc = rsgm_launch_pad_gray(ctx, g, left, gl))) return rc;
-    if ((rc = rsgm_launch_pad_gray(ctx, g, left_vpp, glv))) return rc;
-    if ((rc = rsgm_launch_pad_gray(ctx, g, right_vpp, grv))) return rc;
-    stage_mark(ctx, ST_PAD_GRAY);
-    if ((rc = rsgm_launch_census(ctx, g.B, g.Hp, g.Wp, glv, cl))) return rc;
-    if ((rc = rsgm_launch_census(ctx, g.B, g.Hp, g.Wp, grv, cr))) return rc;
-    stage_mark(ctx, ST_CENSUS);
+    {
+        const u8 *imgs[3] = {left, left_vpp, right_vpp};
+        u8 *grays[3] = {gl, glv, grv};
+        if ((rc = rsgm_launch_pad_gray_n(ctx, g, 3, imgs, grays))) return rc;
+        stage_mark(ctx, ST_PAD_GRAY);
+        const u8 *gsrc[2] = {glv, grv};
+        u32 *cdst[2] = {cl, cr};
+        if ((rc = rsgm_launch_census_n(ctx, g.B, g.Hp, g.Wp, 2, gsrc, cdst))) return rc;
+        stage_mark(ctx, ST_CENSUS);
+    }
 
     u16 lut_h[256];
     int maxp2;
@@ -453,11 +456,9 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
         if ((rc = rsgm_launch_wta_right_t(ctx, g.B, g.Hp, g.Wp, g.D, S, dr0, fu))) return rc;
         stage_mark(ctx, ST_WTA_RIGHT);
     }
-    if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dl0, dl1))) return rc;
-    if ((rc = rsgm_launch_median(ctx, g.B, g.Hp, g.Wp, dr0, dr1))) return rc;
-    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dl1, dl0))) return rc;
-    if ((rc = rsgm_launch_linear_interp_clip(ctx, g.B, g.Hp, g.Wp, dr1, dr0))) return rc;
+    if ((rc = rsgm_launch_median_interp_clip(ctx, g.B, g.Hp, g.Wp, dl0, dl1, dr0, dr1))) return rc;
     stage_mark(ctx, ST_MEDIAN_INTERP);
+    { float *t = dl0; dl0 = dl1; dl1 = t; t = dr0; dr0 = dr1; dr1 = t; } // results are in the *1 buffers
 
     const size_t np = (size_t)g.B * g.H * g.W;
     float *fdc, *fdscr;

@@ -171,8 +171,10 @@ struct RsgmGeom {
 
 // rsgm_kernels.hip
 int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gray);
+int rsgm_launch_pad_gray_n(vppx_ctx *ctx, const RsgmGeom &g, int n, const u8 *const *img, u8 *const *gray); // n <= 3, one launch
 int rsgm_launch_to_nchw(vppx_ctx *ctx, int B, int H, int W, int C, int mult, const u8 *src, void *dst, int bf16);
 int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32 *census);
+int rsgm_launch_census_n(vppx_ctx *ctx, int B, int Hp, int Wp, int n, const u8 *const *gray, u32 *const *census); // n <= 2
 int rsgm_launch_cost(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u32 *cl, const u32 *cr, u16 *dsi);
 int rsgm_launch_guided_dsi(vppx_ctx *ctx, const RsgmGeom &g, u16 *dsi, const float *hints, const float *valid);
 // 8-path aggregation.  Cost source: census pair (dsi == nullptr) or a materialised u16 DSI.
@@ -198,6 +200,9 @@ int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 
 int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
 int rsgm_launch_median(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, float *dst);
 int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src, float *dst);
+// median3x3 + _linear_interpolate + clip of both views in one launch (fused pipeline)
+int rsgm_launch_median_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src_l, float *dst_l, const float *src_r,
+                                   float *dst_r);
 int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
                      float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out);
 
