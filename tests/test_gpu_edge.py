@@ -30,7 +30,7 @@ def eng():
 
 
 @pytest.mark.parametrize("H,W,D,C", [(5, 17, 8, 3), (16, 16, 8, 1), (33, 47, 16, 3), (21, 130, 64, 1), (70, 81, 40, 3),
-                                     (18, 300, 256, 3), (40, 64, 192, 3)])
+                                     (18, 300, 256, 3), (40, 64, 192, 3), (17, 2305, 32, 1)])  # last: wider than 2048
 def test_odd_shapes_fused_vs_oracle(eng, H, W, D, C):
     """Frames that are not multiples of 16, narrower than the search range, gray, tiny D."""
     b = synth.make_batch(2, H, W, max(D, 8), 0.08, seed=H * W, channels=C)

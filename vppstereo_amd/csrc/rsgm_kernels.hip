@@ -1913,6 +1913,7 @@ __global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict
 // right (xr) of the ORIGINAL row; both -> min(v[xl], v[xr]); only one -> that one (border
 // extension); none -> unchanged.  Each thread owns a contiguous segment of the row; the nearest
 // valid index outside the segment comes from one wave-level max/min scan (+ 4 wave carries).
+template <int SEGMAX> // pixels per thread: 8 covers W <= 2048, 32 covers W <= 8192
 __global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__ dm, int H, int W)
 {
     extern __shared__ __attribute__((aligned(16))) float sh_f[]; // [W] original row, [W] result
@@ -1923,7 +1924,7 @@ __global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__
     float *g = dm + ((size_t)f * H + y) * W;
     for (int x = threadIdx.x; x < W; x += 256) val[x] = g[x];
     __syncthreads();
-    const int SEG = (W + 255) / 256; // <= 8 (W <= 2048)
+    const int SEG = (W + 255) / 256; // <= SEGMAX
     const int x0 = threadIdx.x * SEG;
     int lastv = -1, firstv = 0x7FFFFFFF;
     for (int j = 0; j < SEG; j++) {
@@ -1948,15 +1949,15 @@ __global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__
     if (lane == 63) cr = 0x7FFFFFFF;
     for (int w = 0; w < wv; w++) cl = max(cl, s_l[w]);
     for (int w = wv + 1; w < 4; w++) cr = min(cr, s_r[w]);
-    int xl[8];
+    int xl[SEGMAX];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < SEGMAX; j++) {
         const int x = x0 + j;
         if (j < SEG && x < W && val[x] > 0) cl = x;
         xl[j] = cl;
     }
 #pragma unroll
-    for (int j = 7; j >= 0; j--) {
+    for (int j = SEGMAX - 1; j >= 0; j--) {
         const int x = x0 + j;
         if (j >= SEG || x >= W) continue;
         float v = val[x];
@@ -2009,7 +2010,7 @@ int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, cons
     int *runlen = (int *)fd; // scratch [B*H*W] ints
     dim3 grid((g.W + 255) / 256, g.H, g.B);
     const size_t n = (size_t)g.B * g.H * g.W;
-    if (g.W > 2048) { vppx_set_error("frame width %d > 2048 is not supported by the post-processing kernels", g.W); return VPPX_E_UNSUPPORTED; }
+    if (g.W > 8192) { vppx_set_error("frame width %d > 8192 is not supported by the post-processing kernels", g.W); return VPPX_E_UNSUPPORTED; }
     crop_lrc_kernel<<<grid, 256, 0, ctx->stream>>>(dl_pad, dr_pad, fdc, fd8, g.H, g.W, g.Hp, g.Wp, g.pad_t, g.pad_l);
     VPPX_CHECK_LAUNCH();
     VPPX_HIP(hipMemsetAsync(lcount, 0, n * sizeof(int), ctx->stream));
@@ -2022,7 +2023,8 @@ int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, cons
     VPPX_CHECK_LAUNCH();
     speckle_apply_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, lcount, fdc, out, g.H, g.W, 0, 200, subpixel);
     VPPX_CHECK_LAUNCH();
-    interp_bg_rows_kernel<<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
+    if (g.W <= 2048) interp_bg_rows_kernel<8><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
+    else interp_bg_rows_kernel<32><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();
     interp_bg_cols_kernel<<<dim3((g.W + 63) / 64, g.B), 256, 0, ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();
