@@ -26,6 +26,7 @@
 #include <math.h>
 #include <string.h>
 #include <mutex>
+#include <stdlib.h>
 
 #define LG 992 // draws per generator thread (32 passes over the 31-word ring)
 #define RLCAP 8 // per-R-pixel hint list capacity (overflow falls back to the row scan)
@@ -899,6 +900,33 @@ struct MdK {
 __device__ __forceinline__ u32 md_ld(const u8 *p) { return (u32)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void md_st(u8 *p, u8 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Where a chain keeps the pixels it reads and writes.
+//   MemGlobal: in place in HBM/L2 (every access an L2 round trip; any parameters).
+//   MemLds   : the rows a hint row can touch ([y-rad, y+rad], rad = patch radius + wsize_agg_y/2) of the
+//              chain's L and R channel planes live in an LDS ring of NR = 2*rad+1 rows; rows are loaded
+//              once and written back once as the chain moves down the image.  LDS accesses of one wave
+//              execute in order, so a lane-0 store is seen by the next load of any lane.
+struct MemGlobal {
+    u8 *lch, *rch;
+    int W, C;
+    __device__ __forceinline__ u32 ldL(int y, int x) const { return md_ld(lch + ((size_t)y * W + x) * C); }
+    __device__ __forceinline__ u32 ldR(int y, int x) const { return md_ld(rch + ((size_t)y * W + x) * C); }
+    __device__ __forceinline__ void stL(int y, int x, u8 v) const { md_st(lch + ((size_t)y * W + x) * C, v); }
+    __device__ __forceinline__ void stR(int y, int x, u8 v) const { md_st(rch + ((size_t)y * W + x) * C, v); }
+    __device__ __forceinline__ void sync() const { __builtin_amdgcn_s_waitcnt(0); }
+};
+struct MemLds {
+    u8 *sl, *sr; // [NR][W]
+    int W, NR;
+    __device__ __forceinline__ u32 ldL(int y, int x) const { return sl[(y % NR) * W + x]; }
+    __device__ __forceinline__ u32 ldR(int y, int x) const { return sr[(y % NR) * W + x]; }
+    __device__ __forceinline__ void stL(int y, int x, u8 v) const { sl[(y % NR) * W + x] = v; }
+    __device__ __forceinline__ void stR(int y, int x, u8 v) const { sr[(y % NR) * W + x] = v; }
+    // program order is enough inside one wave (LDS executes a wave's accesses in order); the fence only
+    // stops the compiler from moving LDS accesses across it
+    __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+};
+
 // (u8)( V*cc + P*(1.0-cc) )                                   pyx:318,324,332,335 (V double)
 __device__ __forceinline__ u8 mdblend1(double V, float cc, u8 P)
 {
@@ -926,7 +954,8 @@ __device__ __forceinline__ u8 mdblend_r1(double V, float cc, u8 R, float beta)
 }
 
 // colour search: pyx:216-260 (uniform, bins_inside) / :269-313 (per patch pixel)
-__device__ void md_search(const MdK &m, const u8 *lch, const u8 *rch, int cy, int cx, int rcx, bool occluded,
+template <typename Mem>
+__device__ void md_search(const MdK &m, const Mem &mem, int cy, int cx, int rcx, bool occluded,
                           bool bins_inside, u32 *hist /* LDS [256] */, int &pa_out, int &pb_out)
 {
     const int W = m.k.W, H = m.k.H, C = m.k.C;
@@ -934,6 +963,42 @@ __device__ void md_search(const MdK &m, const u8 *lch, const u8 *rch, int cy, in
     int pa = 0, pb = 255;
     int zeros = 0;
     const int ncol = 2 * m.n_agg_x + 1;
+    if (ncol <= 64 && m.n_agg_y <= 1) {
+        // common window (<= 64 columns, <= 3 rows): all samples are fetched before the walk starts
+        const int xx = cx - m.n_agg_x + lane, rx = rcx - m.n_agg_x + lane;
+        const bool inL = (lane < ncol) && xx >= 0 && xx <= W - 1;
+        const bool rin = rx >= 0 && rx <= W - 1;
+        const bool cL0 = inL && (!occluded || !rin), cR0 = inL && rin;
+        int Lr[3], Rr[3];
+        bool rowok[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int yy = cy + r - 1;
+            rowok[r] = (r - 1 >= -m.n_agg_y) && (r - 1 <= m.n_agg_y) && yy >= 0 && yy <= H - 1;
+            Lr[r] = (rowok[r] && cL0) ? (int)mem.ldL(yy, xx) : 0;
+            Rr[r] = (rowok[r] && cR0) ? (int)mem.ldR(yy, rx) : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            if (!rowok[r]) continue; // wave-uniform
+            const bool condL = cL0, condR = cR0;
+            const int Lv = Lr[r], Rv = Rr[r];
+            if (!bins_inside) zeros += __popcll(__ballot(condL && Lv == 0)) + __popcll(__ballot(condR && Rv == 0));
+            int pos = 0;
+            while (true) {
+                const bool candL = condL && Lv > pa && Lv < pb && (2 * lane >= pos);
+                const bool candR = condR && Rv > pa && Rv < pb && (2 * lane + 1 >= pos);
+                const unsigned long long mk = __ballot(candL || candR);
+                if (mk == 0) break;
+                const int fl = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+                const int isL = __builtin_amdgcn_readlane((int)candL, fl);
+                const int p = __builtin_amdgcn_readlane(isL ? Lv : Rv, fl);
+                if (p - pa > pb - p) pb = p;
+                else if (p - pa < pb - p) pa = p;
+                pos = 2 * fl + (isL ? 1 : 2);
+            }
+        }
+    } else
     for (int yw = -m.n_agg_y; yw <= m.n_agg_y; yw++) {
         const int yy = cy + yw;
         if (yy < 0 || yy > H - 1) continue;
@@ -944,8 +1009,8 @@ __device__ void md_search(const MdK &m, const u8 *lch, const u8 *rch, int cy, in
             const bool rin = rx >= 0 && rx <= W - 1;
             const bool condL = inL && (!occluded || !rin);
             const bool condR = inL && rin;
-            const int Lv = condL ? (int)md_ld(lch + ((size_t)yy * W + xx) * C) : 0;
-            const int Rv = condR ? (int)md_ld(rch + ((size_t)yy * W + rx) * C) : 0;
+            const int Lv = condL ? (int)mem.ldL(yy, xx) : 0;
+            const int Rv = condR ? (int)mem.ldR(yy, rx) : 0;
             if (!bins_inside) {
                 zeros += __popcll(__ballot(condL && Lv == 0)) + __popcll(__ballot(condR && Rv == 0));
             }
@@ -955,9 +1020,10 @@ __device__ void md_search(const MdK &m, const u8 *lch, const u8 *rch, int cy, in
                 const bool candR = condR && Rv > pa && Rv < pb && (2 * lane + 1 >= pos);
                 const unsigned long long mk = __ballot(candL || candR);
                 if (mk == 0) break;
-                const int fl = __ffsll((long long)mk) - 1;
-                const int isL = __shfl((int)candL, fl);
-                const int p = __shfl(isL ? Lv : Rv, fl);
+                // the first candidate lane is wave-uniform: scalar lane reads instead of LDS-crossbar shuffles
+                const int fl = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+                const int isL = __builtin_amdgcn_readlane((int)candL, fl);
+                const int p = __builtin_amdgcn_readlane(isL ? Lv : Rv, fl);
                 if (p - pa > pb - p) pb = p;
                 else if (p - pa < pb - p) pa = p;
                 pos = 2 * fl + (isL ? 1 : 2);
@@ -977,8 +1043,8 @@ __device__ void md_search(const MdK &m, const u8 *lch, const u8 *rch, int cy, in
                 const int xx = cx - m.n_agg_x + i, rx = rcx - m.n_agg_x + i;
                 const bool inL = (i < ncol) && xx >= 0 && xx <= W - 1;
                 const bool rin = rx >= 0 && rx <= W - 1;
-                if (inL && (!occluded || !rin)) atomicAdd(&hist[md_ld(lch + ((size_t)yy * W + xx) * C)], 1u);
-                if (inL && rin) atomicAdd(&hist[md_ld(rch + ((size_t)yy * W + rx) * C)], 1u);
+                if (inL && (!occluded || !rin)) atomicAdd(&hist[mem.ldL(yy, xx)], 1u);
+                if (inL && rin) atomicAdd(&hist[mem.ldR(yy, rx)], 1u);
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -992,92 +1058,146 @@ __device__ void md_search(const MdK &m, const u8 *lch, const u8 *rch, int cy, in
     pb_out = pb;
 }
 
+// all hints of row y of chain (f, j), in scan order
+template <typename Mem>
+__device__ __forceinline__ void md_row(const MdK &m, const Mem &mem, int f, int y, u32 *hist, int &pa, int &pb)
+{
+    const VppK &k = m.k;
+    const int W = k.W, H = k.H;
+    const int lane = threadIdx.x & 63;
+    const size_t rowoff = ((size_t)f * H + y) * W;
+    const int cnt = k.row_count[(size_t)f * H + y];
+    for (int i = 0; i < cnt; i++) {
+        const HintRec rec = k.rec[rowoff + i];
+        HintGeo h;
+        decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
+        const int x = h.x;
+        const bool occ = h.occ != 0;
+        const int xd0 = x - h.d0, xd1 = x - h.d1, xd = x - h.d;
+        if (k.uniform) md_search(m, mem, y, x, xd, occ, true, hist, pa, pb); // pyx:216-260
+        for (int yw = -h.nk; yw <= h.nk; yw++)
+            for (int xw = -h.nk; xw <= h.nk; xw++) {
+                const int py = y + yw, pxx = x + xw;
+                if (py < 0 || py > H - 1 || pxx < 0 || pxx > W - 1) continue;      // pyx:267
+                if (k.use_bil && !gate_pass(k, f, h.g, py, pxx)) continue;        // vpp_standalone.py:154
+                if (!k.uniform) md_search(m, mem, py, pxx, xd + xw, occ, false, hist, pa, pb); // pyx:269-313
+                const double V = __ddiv_rn((double)(pa + pb), 2.0);
+                if (0 <= xd0 + xw && xd0 + xw <= W - 1) {                          // pyx:315
+                    if (!occ) {                                                    // pyx:317-324
+                        const u8 Lo = (u8)mem.ldL(py, pxx);
+                        const u8 Ln = mdblend1(V, k.c, Lo);
+                        if (k.interp) {
+                            const int q0 = xd0 + xw;
+                            const u8 R0n = mdblend_r0(V, k.c, (u8)mem.ldR(py, q0), h.beta);
+                            if (lane == 0) { mem.stL(py, pxx, Ln); mem.stR(py, q0, R0n); }
+                            if (0 <= xd1 + xw && xd1 + xw <= W - 1) {
+                                const int q1 = xd1 + xw;
+                                mem.sync();
+                                const u8 R1n = mdblend_r1(V, k.c, (u8)mem.ldR(py, q1), h.beta);
+                                if (lane == 0) mem.stR(py, q1, R1n);
+                            }
+                        } else {
+                            int q = xd + xw;
+                            q = q < 0 ? q + W : q;
+                            const u8 Rn = mdblend1(V, k.c, (u8)mem.ldR(py, q));
+                            if (lane == 0) { mem.stL(py, pxx, Ln); mem.stR(py, q, Rn); }
+                        }
+                    } else if (!k.discard) {                                       // pyx:325-333
+                        if (k.interp) {
+                            const int q0 = xd0 + xw;
+                            int q1 = xd1 + xw;
+                            const bool in1 = q1 >= 0 && q1 <= W - 1;
+                            q1 = q1 < 0 ? q1 + W : q1;
+                            const u8 R0n = mdblend_r0(V, k.c_occ, (u8)mem.ldR(py, q0), h.beta);
+                            if (lane == 0) mem.stR(py, q0, R0n);
+                            mem.sync();
+                            u8 R1v = (u8)mem.ldR(py, q1); // after the r0 store: r1 may alias r0
+                            if (in1) {
+                                R1v = mdblend_r1(V, k.c_occ, R1v, h.beta);
+                                if (lane == 0) mem.stR(py, q1, R1v);
+                                mem.sync();
+                            }
+                            const u8 R0v = (q1 == q0) ? R1v : R0n;
+                            const u8 Ln = blend_l_occ(R0v, R1v, h.beta, k.c, (u8)mem.ldL(py, pxx)); // pyx:330
+                            if (lane == 0) mem.stL(py, pxx, Ln);
+                        } else {
+                            int q = xd + xw;
+                            q = q < 0 ? q + W : q;
+                            const u8 Rn = mdblend1(V, k.c_occ, (u8)mem.ldR(py, q));
+                            const u8 Ln = blend_l_occ_ni(Rn, k.c, (u8)mem.ldL(py, pxx));    // pyx:333
+                            if (lane == 0) { mem.stR(py, q, Rn); mem.stL(py, pxx, Ln); }
+                        }
+                    }
+                } else {                                                           // pyx:334-335
+                    const u8 Ln = mdblend1(V, k.c, (u8)mem.ldL(py, pxx));
+                    if (lane == 0) mem.stL(py, pxx, Ln);
+                }
+                mem.sync(); // stores of this patch pixel land before the next search reads
+            }
+    }
+}
+
+// in-place variant (any parameters)
 __global__ void __launch_bounds__(64) maxdist_kernel(MdK m)
 {
     __shared__ u32 hist[256];
     const VppK &k = m.k;
     const int f = blockIdx.x / k.C, j = blockIdx.x % k.C;
-    const int W = k.W, H = k.H, C = k.C;
+    MemGlobal mem;
+    mem.lch = k.l + (size_t)f * k.H * k.W * k.C + j;
+    mem.rch = k.r + (size_t)f * k.H * k.W * k.C + j;
+    mem.W = k.W;
+    mem.C = k.C;
+    int pa = 0, pb = 255; // pyx:196-197
+    for (int y = 0; y < k.H; y++) md_row(m, mem, f, y, hist, pa, pb);
+}
+
+// LDS-resident variant: `rad` rows above and below the hint row are kept in a ring of NR = 2*rad+1 rows
+__global__ void __launch_bounds__(64) maxdist_lds_kernel(MdK m, int rad)
+{
+    __shared__ u32 hist[256];
+    extern __shared__ __attribute__((aligned(16))) u8 md_rows[]; // [2][NR][W]
+    const VppK &k = m.k;
+    const int f = blockIdx.x / k.C, j = blockIdx.x % k.C;
+    const int W = k.W, H = k.H, C = k.C, NR = 2 * rad + 1;
     const int lane = threadIdx.x & 63;
     u8 *lch = k.l + (size_t)f * H * W * C + j;
     u8 *rch = k.r + (size_t)f * H * W * C + j;
+    MemLds mem;
+    mem.sl = md_rows;
+    mem.sr = md_rows + (size_t)NR * W;
+    mem.W = W;
+    mem.NR = NR;
+    auto load_row = [&](int r) {
+        const int o = (r % NR) * W;
+        for (int x = lane; x < W; x += 64) {
+            mem.sl[o + x] = lch[((size_t)r * W + x) * C];
+            mem.sr[o + x] = rch[((size_t)r * W + x) * C];
+        }
+    };
+    auto store_row = [&](int r) {
+        const int o = (r % NR) * W;
+        for (int x = lane; x < W; x += 64) {
+            lch[((size_t)r * W + x) * C] = mem.sl[o + x];
+            rch[((size_t)r * W + x) * C] = mem.sr[o + x];
+        }
+    };
+    int lo = 0, hi = -1; // rows [lo, hi] are resident
     int pa = 0, pb = 255; // pyx:196-197
     for (int y = 0; y < H; y++) {
-        const size_t rowoff = ((size_t)f * H + y) * W;
-        const int cnt = k.row_count[(size_t)f * H + y];
-        for (int i = 0; i < cnt; i++) {
-            const HintRec rec = k.rec[rowoff + i];
-            HintGeo h;
-            decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
-            const int x = h.x;
-            const bool occ = h.occ != 0;
-            const int xd0 = x - h.d0, xd1 = x - h.d1, xd = x - h.d;
-            if (k.uniform) md_search(m, lch, rch, y, x, xd, occ, true, hist, pa, pb); // pyx:216-260
-            for (int yw = -h.nk; yw <= h.nk; yw++)
-                for (int xw = -h.nk; xw <= h.nk; xw++) {
-                    const int py = y + yw, pxx = x + xw;
-                    if (py < 0 || py > H - 1 || pxx < 0 || pxx > W - 1) continue;      // pyx:267
-                    if (k.use_bil && !gate_pass(k, f, h.g, py, pxx)) continue;        // vpp_standalone.py:154
-                    if (!k.uniform) md_search(m, lch, rch, py, pxx, xd + xw, occ, false, hist, pa, pb); // pyx:269-313
-                    const double V = __ddiv_rn((double)(pa + pb), 2.0);
-                    u8 *lp = lch + ((size_t)py * W + pxx) * C;
-                    if (0 <= xd0 + xw && xd0 + xw <= W - 1) {                          // pyx:315
-                        if (!occ) {                                                    // pyx:317-324
-                            const u8 Lo = (u8)md_ld(lp);
-                            const u8 Ln = mdblend1(V, k.c, Lo);
-                            if (k.interp) {
-                                u8 *r0 = rch + ((size_t)py * W + xd0 + xw) * C;
-                                const u8 R0n = mdblend_r0(V, k.c, (u8)md_ld(r0), h.beta);
-                                if (lane == 0) { md_st(lp, Ln); md_st(r0, R0n); }
-                                if (0 <= xd1 + xw && xd1 + xw <= W - 1) {
-                                    u8 *r1 = rch + ((size_t)py * W + xd1 + xw) * C;
-                                    __builtin_amdgcn_s_waitcnt(0);
-                                    const u8 R1n = mdblend_r1(V, k.c, (u8)md_ld(r1), h.beta);
-                                    if (lane == 0) md_st(r1, R1n);
-                                }
-                            } else {
-                                int q = xd + xw;
-                                q = q < 0 ? q + W : q;
-                                u8 *rd = rch + ((size_t)py * W + q) * C;
-                                const u8 Rn = mdblend1(V, k.c, (u8)md_ld(rd));
-                                if (lane == 0) { md_st(lp, Ln); md_st(rd, Rn); }
-                            }
-                        } else if (!k.discard) {                                       // pyx:325-333
-                            if (k.interp) {
-                                u8 *r0 = rch + ((size_t)py * W + xd0 + xw) * C;
-                                int q1 = xd1 + xw;
-                                const bool in1 = q1 >= 0 && q1 <= W - 1;
-                                q1 = q1 < 0 ? q1 + W : q1;
-                                u8 *r1 = rch + ((size_t)py * W + q1) * C;
-                                const u8 R0n = mdblend_r0(V, k.c_occ, (u8)md_ld(r0), h.beta);
-                                if (lane == 0) md_st(r0, R0n);
-                                __builtin_amdgcn_s_waitcnt(0);
-                                u8 R1v = (u8)md_ld(r1); // after the r0 store: r1 may alias r0
-                                if (in1) {
-                                    R1v = mdblend_r1(V, k.c_occ, R1v, h.beta);
-                                    if (lane == 0) md_st(r1, R1v);
-                                    __builtin_amdgcn_s_waitcnt(0);
-                                }
-                                const u8 R0v = (r1 == r0) ? R1v : R0n;
-                                const u8 Ln = blend_l_occ(R0v, R1v, h.beta, k.c, (u8)md_ld(lp)); // pyx:330
-                                if (lane == 0) md_st(lp, Ln);
-                            } else {
-                                int q = xd + xw;
-                                q = q < 0 ? q + W : q;
-                                u8 *rd = rch + ((size_t)py * W + q) * C;
-                                const u8 Rn = mdblend1(V, k.c_occ, (u8)md_ld(rd));
-                                const u8 Ln = blend_l_occ_ni(Rn, k.c, (u8)md_ld(lp));    // pyx:333
-                                if (lane == 0) { md_st(rd, Rn); md_st(lp, Ln); }
-                            }
-                        }
-                    } else {                                                           // pyx:334-335
-                        const u8 Ln = mdblend1(V, k.c, (u8)md_ld(lp));
-                        if (lane == 0) md_st(lp, Ln);
-                    }
-                    __builtin_amdgcn_s_waitcnt(0); // stores of this patch pixel land before the next search reads
-                }
+        if (k.row_count[(size_t)f * H + y] == 0) continue;
+        const int nlo = max(0, y - rad), nhi = min(H - 1, y + rad);
+        if (nlo > hi) { // no overlap with what is resident: write everything back, start afresh
+            for (int r = lo; r <= hi; r++) store_row(r);
+            lo = nlo;
+            hi = nlo - 1;
         }
+        for (; lo < nlo; lo++) store_row(lo); // rows the chain has left behind
+        for (; hi < nhi;) load_row(++hi);
+        __builtin_amdgcn_s_waitcnt(0);
+        md_row(m, mem, f, y, hist, pa, pb);
     }
+    for (int r = lo; r <= hi; r++) store_row(r);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1151,7 +1271,14 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         m.k.uniform = p.uniform_color != 0;
         m.n_agg_x = (p.wsize_agg_x - 1) / 2;
         m.n_agg_y = (p.wsize_agg_y - 1) / 2;
-        maxdist_kernel<<<dim3(g.B * g.C), 64, 0, ctx->stream>>>(m);
+        // rows one hint row can touch: patch radius + vertical half window of the colour search
+        const int rad = k.n + m.n_agg_y;
+        const size_t lds = (size_t)2 * (2 * rad + 1) * g.W;
+        if (lds <= 60 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
+            maxdist_lds_kernel<<<dim3(g.B * g.C), 64, lds, ctx->stream>>>(m, rad);
+        } else {
+            maxdist_kernel<<<dim3(g.B * g.C), 64, 0, ctx->stream>>>(m);
+        }
         VPPX_CHECK_LAUNCH();
         stage_mark(ctx, ST_VPP_APPLY);
         return 0;
