@@ -11,6 +11,6 @@ for B in (1, 8):
     h = torch.from_numpy(np.ascontiguousarray(b["hints"][idx])).to(dev)
     for it in range(2):
         torch.cuda.synchronize(); t=time.time()
-        eng.vpp(l, r, h, seed=1, method=1)
+        eng.vpp(l, r, h, seed=1, method=1, uniform_color=int(os.environ.get("UNI", "0")))
         torch.cuda.synchronize(); dt=time.time()-t
     print("maxDistance B=%d: %.1f ms (%.1f ms/frame)" % (B, dt*1e3, dt*1e3/B))

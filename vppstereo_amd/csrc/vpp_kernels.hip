@@ -918,10 +918,17 @@ struct MemGlobal {
 struct MemLds {
     u8 *sl, *sr; // [NR][W]
     int W, NR;
-    __device__ __forceinline__ u32 ldL(int y, int x) const { return sl[(y % NR) * W + x]; }
-    __device__ __forceinline__ u32 ldR(int y, int x) const { return sr[(y % NR) * W + x]; }
-    __device__ __forceinline__ void stL(int y, int x, u8 v) const { sl[(y % NR) * W + x] = v; }
-    __device__ __forceinline__ void stR(int y, int x, u8 v) const { sr[(y % NR) * W + x] = v; }
+    int row0, slot0; // current hint row and its ring slot (row0 % NR): rows within +-rad map without a division
+    __device__ __forceinline__ int off(int y) const
+    {
+        int sidx = slot0 + (y - row0);
+        sidx = sidx < 0 ? sidx + NR : (sidx >= NR ? sidx - NR : sidx);
+        return sidx * W;
+    }
+    __device__ __forceinline__ u32 ldL(int y, int x) const { return sl[off(y) + x]; }
+    __device__ __forceinline__ u32 ldR(int y, int x) const { return sr[off(y) + x]; }
+    __device__ __forceinline__ void stL(int y, int x, u8 v) const { sl[off(y) + x] = v; }
+    __device__ __forceinline__ void stR(int y, int x, u8 v) const { sr[off(y) + x] = v; }
     // program order is enough inside one wave (LDS executes a wave's accesses in order); the fence only
     // stops the compiler from moving LDS accesses across it
     __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
@@ -978,24 +985,31 @@ __device__ void md_search(const MdK &m, const Mem &mem, int cy, int cx, int rcx,
             Lr[r] = (rowok[r] && cL0) ? (int)mem.ldL(yy, xx) : 0;
             Rr[r] = (rowok[r] && cR0) ? (int)mem.ldR(yy, rx) : 0;
         }
+        // The walk itself runs on scalar state: pa, pb and the "still to come" lane masks are wave-uniform, so an
+        // iteration is two vector range tests + two ballots + a handful of scalar ops + one lane read.
+        const unsigned long long baseL = __ballot(cL0), baseR = __ballot(cR0);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             if (!rowok[r]) continue; // wave-uniform
-            const bool condL = cL0, condR = cR0;
             const int Lv = Lr[r], Rv = Rr[r];
-            if (!bins_inside) zeros += __popcll(__ballot(condL && Lv == 0)) + __popcll(__ballot(condR && Rv == 0));
-            int pos = 0;
+            if (!bins_inside) zeros += __popcll(__ballot(cL0 && Lv == 0)) + __popcll(__ballot(cR0 && Rv == 0));
+            unsigned long long aliveL = baseL, aliveR = baseR;
             while (true) {
-                const bool candL = condL && Lv > pa && Lv < pb && (2 * lane >= pos);
-                const bool candR = condR && Rv > pa && Rv < pb && (2 * lane + 1 >= pos);
-                const unsigned long long mk = __ballot(candL || candR);
-                if (mk == 0) break;
-                const int fl = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
-                const int isL = __builtin_amdgcn_readlane((int)candL, fl);
-                const int p = __builtin_amdgcn_readlane(isL ? Lv : Rv, fl);
+                // pa < v < pb  <=>  (unsigned)(v - pa - 1) < (unsigned)(pb - pa - 1)
+                const u32 wdt = (u32)(pb - pa - 1);
+                const unsigned long long mL = __ballot((u32)(Lv - pa - 1) < wdt) & aliveL;
+                const unsigned long long mR = __ballot((u32)(Rv - pa - 1) < wdt) & aliveR;
+                if ((mL | mR) == 0) break;
+                const int fL = mL ? __ffsll((long long)mL) - 1 : 64;
+                const int fR = mR ? __ffsll((long long)mR) - 1 : 64;
+                const bool isL = fL <= fR; // sequence order: left sample of a column before its right sample
+                const int fl = __builtin_amdgcn_readfirstlane(isL ? fL : fR);
+                const int p = isL ? __builtin_amdgcn_readlane(Lv, fl) : __builtin_amdgcn_readlane(Rv, fl);
                 if (p - pa > pb - p) pb = p;
                 else if (p - pa < pb - p) pa = p;
-                pos = 2 * fl + (isL ? 1 : 2);
+                const unsigned long long upto = (fl >= 63) ? ~0ull : ((2ull << fl) - 1); // columns <= fl
+                aliveL = baseL & ~upto;
+                aliveR = baseR & ~(isL ? (upto >> 1) : upto);                          // right sample of column fl still to come
             }
         }
     } else
@@ -1195,6 +1209,8 @@ __global__ void __launch_bounds__(64) maxdist_lds_kernel(MdK m, int rad)
         for (; lo < nlo; lo++) store_row(lo); // rows the chain has left behind
         for (; hi < nhi;) load_row(++hi);
         __builtin_amdgcn_s_waitcnt(0);
+        mem.row0 = y;
+        mem.slot0 = y % NR;
         md_row(m, mem, f, y, hist, pa, pb);
     }
     for (int r = lo; r <= hi; r++) store_row(r);
