@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--cpu-parallel", action="store_true", help="also time the CPU port on up to 32 host cores")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
