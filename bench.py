@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
                     help="other BASELINE configs, e.g. --shape 375 1242 192 0.05 (KITTI) or 1536 2048 256 0.01")
+    ap.add_argument("--uniform-random", action="store_true",
+                    help="uniform-random u8 images and hint values (the variant SURVEY section 6 timed on the CPU) "
+                         "instead of the textured scenes; GPU timing only")
     return ap.parse_args()
 
 
@@ -134,7 +137,13 @@ def main():
     lo, hi = vdist.shard_range(n_total, rank, world)
     # synthetic frames: a few distinct scenes tiled over the batch (generation is host-side numpy)
     n_unique = min(B, 4)
-    base = synth.make_batch(n_unique, H, W, D, P_HINTS, seed=1234, frame0=lo)
+    if args.uniform_random:
+        trip = [synth.uniform_random_pair(H, W, D, P_HINTS, seed=lo + i) for i in range(n_unique)]
+        base = {"left": np.stack([t[0] for t in trip]), "right": np.stack([t[1] for t in trip]),
+                "hints": np.stack([t[2] for t in trip])}
+        args.cpu_frames = 0  # the CPU leg regenerates the textured frames: not comparable
+    else:
+        base = synth.make_batch(n_unique, H, W, D, P_HINTS, seed=1234, frame0=lo)
     idx = [i % n_unique for i in range(B)]
     left = torch.from_numpy(np.ascontiguousarray(base["left"][idx])).to(dev)
     right = torch.from_numpy(np.ascontiguousarray(base["right"][idx])).to(dev)
@@ -231,7 +240,8 @@ def main():
             "metric": f"Mdisparities/s (HxWxD / s) VPP+rSGM at {H}x{W}xD={D}",
             "value": round(value, 1), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u16",
+            "data": "synthetic (uniform random u8)" if args.uniform_random else "synthetic",
             "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
                                    f"{B} frames/GPU/step resident in HBM", "frames_per_step": n_total,
                        "H": H, "W": W, "D": D, "hint_density": P_HINTS},
