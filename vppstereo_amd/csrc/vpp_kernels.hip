@@ -1248,6 +1248,10 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
 {
     if (g.C < 1 || g.C > 4) { vppx_set_error("channels must be 1..4 (got %d)", g.C); return VPPX_E_INVALID_ARG; }
     if (p.wsize < 1 || p.wsize > 31) { vppx_set_error("wsize must be in 1..31 (got %d)", p.wsize); return VPPX_E_INVALID_ARG; }
+    if (g.W > 32767 || g.H > 65535) { // hint ranges are int16 columns, list ids are (row << 16 | index in row)
+        vppx_set_error("frames larger than 65535 x 32767 are not supported (got %d x %d)", g.H, g.W);
+        return VPPX_E_UNSUPPORTED;
+    }
     VppK k;
     k.B = g.B; k.H = g.H; k.W = g.W; k.C = g.C;
     k.n = (p.wsize - 1) / 2;
