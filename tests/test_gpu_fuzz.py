@@ -61,3 +61,39 @@ def test_compute_rsgm_random_parameters(seed):
     got = compute_rsgm(*args, **kw)
     assert got.dtype == np.float32 and got.shape == want.shape
     assert np.array_equal(want, got), (seed, kw.get("dmax"), float(np.max(np.abs(want - got))))
+
+
+@pytest.mark.parametrize("seed", list(range(300, 316)))
+def test_fused_batched_random_parameters(seed):
+    """Engine.vpp_rsgm (the call bench.py times) with random batch sizes (both lane layouts of the
+    aggregation: B < 8 and B >= 8, XCD-aware block map at B % 8 == 0), shapes and parameters."""
+    import torch
+    from vppstereo_amd.engine import Engine
+    rng = np.random.default_rng(seed)
+    B = int(rng.choice([1, 2, 5, 8, 9, 16]))
+    H, W = int(rng.integers(8, 48)), int(rng.integers(16, 120))
+    D = int(rng.choice([16, 64, 128, 192, 256]))
+    dens = float(rng.choice([0.02, 0.1, 0.5]))
+    b = synth.make_batch(B, H, W, max(D, 8), dens, seed=seed)
+    occ = ((rng.random((B, H, W)) < 0.25) & (b["hints"] > 0)).astype(np.uint8)
+    vkw = dict(wsize=int(rng.choice([1, 3, 5])), direction=int(rng.integers(2)), uniform_color=int(rng.integers(2)),
+               interpolate=int(rng.integers(2)), discard_occluded=int(rng.integers(2)), c_occ=float(rng.choice([0.0, 0.3])))
+    rkw = dict(dmax=D, p1=int(rng.choice([5, 11])), p2min=int(rng.choice([17, 40])), gamma=int(rng.choice([35, 80])),
+               uniqueness=float(rng.choice([0.95, 0.7])), subpixel=int(rng.integers(2)))
+    eng = Engine()
+    dev = eng.device
+    lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+    rv = torch.empty_like(lv)
+    out = eng.vpp_rsgm(torch.from_numpy(b["left"]).to(dev), torch.from_numpy(b["right"]).to(dev), torch.from_numpy(b["hints"]).to(dev),
+                       g_occ=torch.from_numpy(occ).to(dev), l_vpp=lv, r_vpp=rv, seed=seed, vpp_kw=vkw, rsgm_kw=rkw)
+    torch.cuda.synchronize()
+    out, lv, rv = out.cpu().numpy(), lv.cpu().numpy(), rv.cpu().numpy()
+    for f in range(B):
+        oracle.init_rand(seed + f)
+        a0, b0 = b["left"][f].copy(), b["right"][f].copy()
+        oracle.virtual_projection_scan_rnd(a0, b0, b["hints"][f], W, H, 3, bool(vkw["uniform_color"]), vkw["wsize"], vkw["direction"],
+                                           0.4, vkw["c_occ"], occ[f], bool(vkw["discard_occluded"]), bool(vkw["interpolate"]))
+        assert np.array_equal(a0, lv[f]) and np.array_equal(b0, rv[f]), (seed, f, vkw)
+        want = oracle.compute_rsgm(b["left"][f], a0, b0, dmax=D, p1=rkw["p1"], p2min=rkw["p2min"], gamma=rkw["gamma"],
+                                   uniqueness=rkw["uniqueness"], subpixel=bool(rkw["subpixel"]))
+        assert np.array_equal(want, out[f]), (seed, f, B, H, W, D, rkw)
