@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
                     help="other BASELINE configs, e.g. --shape 375 1242 192 0.05 (KITTI) or 1536 2048 256 0.01")
+    ap.add_argument("--graph", action="store_true",
+                    help="run on a side stream with hipGraph replay of the fused call (small batches are launch-bound)")
     ap.add_argument("--uniform-random", action="store_true",
                     help="uniform-random u8 images and hint values (the variant SURVEY section 6 timed on the CPU) "
                          "instead of the textured scenes; GPU timing only")
@@ -131,6 +133,9 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
     eng = Engine(dev_index)
+    if args.graph:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # stream capture needs a non-default stream
+        eng.set_graph_mode(True)
 
     B = args.batch
     n_total = B * world
@@ -259,6 +264,8 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stages.items()},
             "device": eng.ctx.device_name,
         }
+        if args.graph:
+            result["graph_replays"] = eng.graph_replays()
         if world == 1 and args.cpu_frames > 0:
             gpu_out = out[: min(args.cpu_frames, n_unique)].cpu().numpy()
             result["cpu_baseline"], epe = cpu_baseline(min(args.cpu_frames, n_unique), gpu_out)

@@ -221,6 +221,12 @@ int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float
 /* Time `iters` back-to-back launches of the dominant kernel (8-path aggregation) on the
  * context's stream with hipEvents around the kernel only; returns average ms per launch
  * in *ms_out.  Operates on the workspace state left by the last vppx_rsgm_dev call. */
+/* hipGraph replay of vppx_vpp_rsgm_dev (also VPPX_GRAPH=1): with the mode on, the second call with identical
+ * shapes, parameters, pointers and stream is stream-captured and later identical calls launch the instantiated
+ * graph (one launch instead of ~40: matters for small batches).  Needs a non-default stream (vppx_set_stream);
+ * where capture is not possible the call silently stays on the eager path.  vppx_graph_replays counts launches. */
+int vppx_set_graph_mode(vppx_ctx *ctx, int enable);
+long vppx_graph_replays(vppx_ctx *ctx);
 int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out);
 /* Average duration (ms) of the aggregation kernel over the last `last_n` launches the pipeline made
  * on this context, from hipEvent pairs recorded around every launch on its launch stream (ring of

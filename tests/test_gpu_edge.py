@@ -116,3 +116,36 @@ def test_batch_of_eight_uses_xcd_aware_block_map(eng):
         lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
         assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), f
         assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D), out[f]), f
+
+
+def test_graph_replay_matches_eager(eng):
+    """hipGraph replay of the fused call (vppx_set_graph_mode): call 1 eager, call 2 captured, calls 3+ launched
+    from the instantiated graph; results identical to the eager path and the oracle."""
+    import torch
+    b = synth.make_batch(2, 40, 96, 64, 0.06, seed=21)
+    want, lv0, rv0 = _fused(eng, b, 64, seed=5)
+    dev = eng.device
+    left, right, hints = (torch.from_numpy(b[k]).to(dev) for k in ("left", "right", "hints"))
+    out = torch.empty((2, 40, 96), dtype=torch.float32, device=dev)
+    lv = torch.empty((2, 40, 96, 3), dtype=torch.uint8, device=dev)
+    rv = torch.empty_like(lv)
+    side = torch.cuda.Stream(device=dev)
+    n0 = eng.graph_replays()
+    eng.set_graph_mode(True)
+    try:
+        with torch.cuda.stream(side):
+            for it in range(5):
+                out.zero_(); lv.zero_()
+                eng.vpp_rsgm(left, right, hints, out=out, l_vpp=lv, r_vpp=rv, seed=5, rsgm_kw=dict(dmax=64))
+                side.synchronize()
+                assert np.array_equal(out.cpu().numpy(), want), it
+                assert np.array_equal(lv.cpu().numpy(), lv0) and np.array_equal(rv.cpu().numpy(), rv0), it
+        assert eng.graph_replays() - n0 >= 3        # calls 2..5 went through the graph
+        # a different seed is a different key: eager again, then re-captured
+        with torch.cuda.stream(side):
+            eng.vpp_rsgm(left, right, hints, out=out, l_vpp=lv, r_vpp=rv, seed=6, rsgm_kw=dict(dmax=64))
+            side.synchronize()
+        want6, _, _ = _fused(eng, b, 64, seed=6)
+        assert np.array_equal(out.cpu().numpy(), want6)
+    finally:
+        eng.set_graph_mode(False)

@@ -64,6 +64,8 @@ int ws_reserve(vppx_ctx *ctx, WsSlot s, size_t bytes, void **out)
     DevBuf &b = ctx->ws[s];
     if (bytes == 0) bytes = 16;
     if (b.cap < bytes) {
+        if (ctx->capturing) { vppx_set_error("workspace growth during graph capture"); return VPPX_E_HIP; }
+        ctx->ws_gen++;
         if (b.p) {
             // the old buffer may still be referenced by enqueued kernels
             VPPX_HIP(hipStreamSynchronize(ctx->stream));
@@ -130,6 +132,8 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
     {
         const char *e = getenv("VPPX_VERT");
         if (e) ctx->use_vert = atoi(e);
+        e = getenv("VPPX_GRAPH");
+        if (e && atoi(e) > 0) ctx->graph_mode = true;
         e = getenv("VPPX_SUBSTREAMS");
         if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     }
@@ -150,6 +154,7 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
         if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
     if (ctx->ev_created)
         for (int i = 0; i <= VPPX_MAX_STAGES; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->agg_ev_created)
         for (int j = 0; j < 2; j++)
             for (int i = 0; i < vppx_ctx::AGG_RING; i++) (void)hipEventDestroy(ctx->agg_ev[j][i]);
@@ -159,6 +164,17 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
+
+extern "C" int vppx_set_graph_mode(vppx_ctx *ctx, int enable)
+{
+    if (!ctx) return VPPX_E_INVALID_ARG;
+    ctx->graph_mode = enable != 0;
+    if (!enable && ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; ctx->have_gkey = false; }
+    ctx->have_lastkey = false;
+    return 0;
+}
+
+extern "C" long vppx_graph_replays(vppx_ctx *ctx) { return ctx ? ctx->graph_replays : 0; }
 
 extern "C" int vppx_set_stream(vppx_ctx *ctx, void *hip_stream)
 {
@@ -218,14 +234,14 @@ extern "C" int vppx_enable_stage_timing(vppx_ctx *ctx, int enable)
 
 void stage_begin(vppx_ctx *ctx)
 {
-    if (!ctx->stage_timing) return;
+    if (!ctx->stage_timing || ctx->capturing) return;
     ctx->n_stages = 0;
     (void)hipEventRecord(ctx->ev[0], ctx->stream);
 }
 
 void stage_mark(vppx_ctx *ctx, int stage)
 {
-    if (!ctx->stage_timing || ctx->n_stages >= VPPX_MAX_STAGES) return;
+    if (!ctx->stage_timing || ctx->capturing || ctx->n_stages >= VPPX_MAX_STAGES) return;
     ctx->stage_id[ctx->n_stages] = stage;
     ctx->n_stages++;
     (void)hipEventRecord(ctx->ev[ctx->n_stages], ctx->stream);
@@ -383,11 +399,15 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 for (int i = 0; i < vppx_ctx::AGG_RING; i++) VPPX_HIP(hipEventCreate(&ctx->agg_ev[j][i]));
             ctx->agg_ev_created = true;
         }
-        const int slot = (int)(ctx->agg_calls % vppx_ctx::AGG_RING);
-        VPPX_HIP(hipEventRecord(ctx->agg_ev[0][slot], ctx->stream));
-        if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes, 0xFF))) return rc;
-        VPPX_HIP(hipEventRecord(ctx->agg_ev[1][slot], ctx->stream));
-        ctx->agg_calls++;
+        if (ctx->capturing) { // event records stay out of a captured graph
+            if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes, 0xFF))) return rc;
+        } else {
+            const int slot = (int)(ctx->agg_calls % vppx_ctx::AGG_RING);
+            VPPX_HIP(hipEventRecord(ctx->agg_ev[0][slot], ctx->stream));
+            if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes, 0xFF))) return rc;
+            VPPX_HIP(hipEventRecord(ctx->agg_ev[1][slot], ctx->stream));
+            ctx->agg_calls++;
+        }
         for (int k = 0; k < 8; k++) vols[k] = (const u8 *)paths + (size_t)k * ncell * elem_bytes;
         nvol = 8;
     }
@@ -424,12 +444,16 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
         stage_mark(ctx, ST_CENSUS);
     }
 
-    u16 lut_h[256];
-    int maxp2;
-    p2_lut_host(p, lut_h, &maxp2);
     u16 *lut_d;
     if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
-    VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->lut_valid || ctx->lut_p2min != p.p2min || ctx->lut_gamma != p.gamma || ctx->lut_alpha != p.alpha) {
+        if (ctx->capturing) { vppx_set_error("penalty table changed during graph capture"); return VPPX_E_HIP; }
+        p2_lut_host(p, ctx->lut_host, &ctx->lut_maxp2);
+        VPPX_HIP(hipMemcpyAsync(lut_d, ctx->lut_host, sizeof(ctx->lut_host), hipMemcpyHostToDevice, ctx->stream));
+        ctx->lut_p2min = p.p2min; ctx->lut_gamma = p.gamma; ctx->lut_alpha = p.alpha;
+        ctx->lut_valid = true;
+    }
+    const int maxp2 = ctx->lut_maxp2;
     // per-path values are bounded by Cmax + P2max (L_r - min L_r <= P2): bytes suffice when that is < 256
     const void *vols[8];
     int nvol = 0, elem_bytes = 1;
@@ -702,6 +726,57 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
     if ((rc = check_vpp_params(*vp))) return rc;
     if ((rc = check_rsgm_params(*rp))) return rc;
     const int nsub = (ctx->stage_timing || ctx->is_child) ? 1 : (B >= 2 * ctx->nsub ? ctx->nsub : 1);
+    if (nsub <= 1 && ctx->graph_mode && !ctx->stage_timing) {
+        // hipGraph replay: launch-bound small batches pay ~40 kernel launches per call otherwise
+        vppx_ctx::GraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.B = B; key.H = H; key.W = W; key.C = C; key.vp = *vp; key.rp = *rp;
+        key.ptr[0] = left; key.ptr[1] = right; key.ptr[2] = g; key.ptr[3] = g_occ; key.ptr[4] = l_vpp; key.ptr[5] = r_vpp;
+        key.ptr[6] = disp_out;
+        key.stream = (void *)ctx->stream;
+        key.ws_gen = ctx->ws_gen;
+        if (ctx->gexec && ctx->have_gkey && memcmp(&key, &ctx->gkey, sizeof(key)) == 0) {
+            VPPX_HIP(hipGraphLaunch(ctx->gexec, ctx->stream));
+            ctx->graph_replays++;
+            return 0;
+        }
+        if (ctx->have_lastkey && memcmp(&key, &ctx->lastkey, sizeof(key)) == 0) {
+            // second identical call (the first one sized the workspace and warmed every lazy init): capture it
+            if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; ctx->have_gkey = false; }
+            hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                ctx->capturing = true;
+                rc = vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+                ctx->capturing = false;
+                hipGraph_t graph = nullptr;
+                e = hipStreamEndCapture(ctx->stream, &graph);
+                if (rc == 0 && e == hipSuccess && graph) {
+                    e = hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(graph);
+                    if (e == hipSuccess) {
+                        ctx->gkey = key;
+                        ctx->have_gkey = true;
+                        ctx->graph_captures++;
+                        VPPX_HIP(hipGraphLaunch(ctx->gexec, ctx->stream));
+                        ctx->graph_replays++;
+                        return 0;
+                    }
+                    ctx->gexec = nullptr;
+                } else if (graph) {
+                    (void)hipGraphDestroy(graph);
+                }
+            }
+            // capture is not possible here (e.g. the legacy default stream): stay on the eager path
+            (void)hipGetLastError();
+            ctx->graph_mode = false;
+            return vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+        }
+        rc = vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+        key.ws_gen = ctx->ws_gen; // the workspace as this call left it
+        ctx->lastkey = key;
+        ctx->have_lastkey = (rc == 0);
+        return rc;
+    }
     if (nsub <= 1) return vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
     // Frames are independent: split the batch over child contexts (own stream + arena).  The
     // latency-bound stages of one part (VPP replay, post-processing) then overlap the

@@ -123,6 +123,27 @@ struct vppx_ctx {
     hipEvent_t agg_ev[2][AGG_RING];
     bool agg_ev_created = false;
     long agg_calls = 0;
+    // P2 look-up table: host copy kept alive for the asynchronous upload, re-sent only when the penalties change
+    u16 lut_host[256];
+    bool lut_valid = false;
+    int lut_p2min = 0, lut_gamma = 0, lut_maxp2 = 0;
+    float lut_alpha = 0.f;
+    // hipGraph replay of the fused call (VPPX_GRAPH=1 / vppx_set_graph_mode): the second identical call
+    // (same shapes, parameters and pointers) is stream-captured, later ones launch the instantiated graph
+    struct GraphKey {
+        int B, H, W, C;
+        VppxVppParams vp;
+        VppxRsgmParams rp;
+        const void *ptr[7];
+        void *stream;
+        unsigned long ws_gen;
+    };
+    bool graph_mode = false, capturing = false;
+    bool have_gkey = false, have_lastkey = false;
+    GraphKey gkey, lastkey;
+    hipGraphExec_t gexec = nullptr;
+    unsigned long ws_gen = 0;      // bumped whenever a workspace buffer is (re)allocated
+    long graph_replays = 0, graph_captures = 0;
     // stage timing
     bool stage_timing = false;
     int n_stages = 0;

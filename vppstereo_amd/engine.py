@@ -187,6 +187,14 @@ class Engine:
                                                 int(bool(little_endian)), _ptr(out)))
         return out
 
+    def set_graph_mode(self, enable=True):
+        """hipGraph replay of repeated identical vpp_rsgm calls (same tensors, parameters and stream; needs a
+        non-default torch stream).  `graph_replays()` counts the calls served by a graph launch."""
+        _lib.check(self.lib.vppx_set_graph_mode(self.ctx.handle, int(bool(enable))))
+
+    def graph_replays(self):
+        return int(self.lib.vppx_graph_replays(self.ctx.handle))
+
     # ---- measurement helpers (bench.py) ----
     def time_aggregate(self, iters=10):
         ms = C.c_float()
