@@ -192,3 +192,21 @@ def test_network_input_handoff_matches_reference_glue():
     lv = torch.arange(256, dtype=torch.uint8).reshape(1, 16, 16, 1).to(eng.device)
     back = (eng.to_network_input(lv, pad_multiple=1).cpu() * 255).numpy().astype(np.uint8).reshape(-1)
     assert np.array_equal(back, np.arange(256, dtype=np.uint8))
+
+
+def test_stage_api_between_fused_calls_does_not_poison_the_penalty_table():
+    """The fused path caches its P2 table on the device; aggregate_SSE (stage API) writes another one into
+    the same buffer: the next fused call must re-upload its own."""
+    from vppstereo_amd import pyrSGM
+    from vppstereo_amd.rsgm import compute_rsgm
+    fr = synth.make_frame(40, 64, 32, 0.05, seed=8)
+    oracle.init_rand(3)
+    lv, rv = oracle.vpp(fr["left"], fr["right"], fr["hints"])
+    want = oracle.compute_rsgm(fr["left"], lv, rv, dmax=32)
+    assert np.array_equal(compute_rsgm(fr["left"], lv, rv, dmax=32), want)
+    gl = oracle.rgb2gray(fr["left"])
+    gl16 = np.ascontiguousarray(np.pad(gl, ((4, 4), (0, 0)), mode="edge"))        # 48 x 64
+    dsi = np.random.default_rng(1).integers(0, 25, (48, 64, 32)).astype(np.uint16)
+    S = np.zeros_like(dsi)
+    pyrSGM.aggregate_SSE(gl16, dsi, S, 64, 48, 32, 3, 90, 2.0, 200)               # very different penalties
+    assert np.array_equal(compute_rsgm(fr["left"], lv, rv, dmax=32), want)

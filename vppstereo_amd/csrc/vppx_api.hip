@@ -979,6 +979,7 @@ extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t 
     if ((rc = upload(ctx, WS_DSI, dsi, nc * sizeof(u16), &ddsi))) return rc;
     if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
     VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
+    ctx->lut_valid = false; // the fused path's cached table was overwritten
     if ((rc = ws_reserve(ctx, WS_PATHS, nc * 8 * 2, &paths))) return rc;
     if ((rc = ws_get(ctx, WS_S, nc, &S))) return rc;
     if ((rc = rsgm_launch_paths(ctx, 1, h, w, dmax, (const u8 *)dimg, nullptr, nullptr, (const u16 *)ddsi, lut_d, p1, paths, 2, 0xFF))) return rc;
