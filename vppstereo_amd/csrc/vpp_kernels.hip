@@ -395,9 +395,8 @@ static int ensure_rand_table(vppx_ctx *ctx, int nblk, const u32 **tab_out)
             poly_mulmod(&g_tab_host[(size_t)(b - 1) * 31], step, &g_tab_host[(size_t)b * 31]);
     }
     if (g_tab_dev_n < nblk) {
-        // grow with slack; the old table may still be in use by enqueued kernels -> sync first
-        VPPX_HIP(hipStreamSynchronize(ctx->stream));
-        if (g_tab_dev) VPPX_HIP(hipFree(g_tab_dev));
+        // grow: the old (shorter, prefix-identical) table is left alive on purpose -- kernels enqueued by other
+        // contexts / streams and captured graphs may still reference it (a few MB per growth at most)
         g_tab_dev = nullptr;
         g_tab_dev_n = 0;
         VPPX_HIP(hipMalloc((void **)&g_tab_dev, (size_t)nblk * 31 * sizeof(u32)));

@@ -735,12 +735,14 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
         key.ptr[6] = disp_out;
         key.stream = (void *)ctx->stream;
         key.ws_gen = ctx->ws_gen;
-        if (ctx->gexec && ctx->have_gkey && memcmp(&key, &ctx->gkey, sizeof(key)) == 0) {
+        // the graph does not contain the penalty-table upload: it must still be the table of these parameters
+        const bool lut_ok = ctx->lut_valid && ctx->lut_p2min == rp->p2min && ctx->lut_gamma == rp->gamma && ctx->lut_alpha == rp->alpha;
+        if (lut_ok && ctx->gexec && ctx->have_gkey && memcmp(&key, &ctx->gkey, sizeof(key)) == 0) {
             VPPX_HIP(hipGraphLaunch(ctx->gexec, ctx->stream));
             ctx->graph_replays++;
             return 0;
         }
-        if (ctx->have_lastkey && memcmp(&key, &ctx->lastkey, sizeof(key)) == 0) {
+        if (lut_ok && ctx->have_lastkey && memcmp(&key, &ctx->lastkey, sizeof(key)) == 0) {
             // second identical call (the first one sized the workspace and warmed every lazy init): capture it
             if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; ctx->have_gkey = false; }
             hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
