@@ -182,10 +182,24 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
+    gather_note = None
     if world > 1 and not args.no_gather:
-        # RCCL creates its send/recv channels on first use: do that outside the timed region even with --warmup 0
-        vdist.gather_disparities_async(outs[0], n_total, dst=0).wait()
-        torch.cuda.synchronize()
+        # RCCL creates its send/recv channels on first use: do that outside the timed region even with --warmup 0.
+        # Should the gather be unusable on this node, every rank agrees to keep its shard local (the data path
+        # has no collective; the gather only delivers results to rank 0) and the line says so.
+        ok = 1
+        try:
+            vdist.gather_disparities_async(outs[0], n_total, dst=0).wait()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"[bench] rank {rank}: result gather failed ({type(e).__name__}: {e}); running without it", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            args.no_gather = True
+            gather_note = "result gather to rank 0 unavailable: shards stay on their ranks"
+
     for _ in range(args.warmup):
         step()
     drain()
@@ -266,6 +280,8 @@ def main():
         }
         if args.graph:
             result["graph_replays"] = eng.graph_replays()
+        if world > 1:
+            result["config"]["result_gather"] = gather_note or ("off" if args.no_gather else "async gather to rank 0, overlapped")
         if world == 1 and args.cpu_frames > 0:
             gpu_out = out[: min(args.cpu_frames, n_unique)].cpu().numpy()
             result["cpu_baseline"], epe = cpu_baseline(min(args.cpu_frames, n_unique), gpu_out)
