@@ -774,200 +774,6 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
 }
 
 // ---------------------------------------------------------------------------------------
-// EXPERIMENT (not on the product path): raster-order sweep of four paths at once.
-// Pass 0 carries W, NW, N, NE top-down / left-to-right; pass 1 (mirror) is the same program on the
-// point-mirrored frame and carries E, SE, S, SW.  16 lanes own one pixel (12 disparities each), the
-// four lane groups of a wave own four consecutive rows, skewed by two pixels per row (NE needs the
-// row above two pixels ahead).  Each step a group receives the NE/N/NW vectors the group above
-// produced one step earlier (pixel x+1 of the row above): NE is used at once, N after one step and
-// NW after two (delay lines).  The top group of a wave gets them from the last row of the wave
-// above through a global hand-off buffer + progress counter (agent-scope atomics; a wave only
-// ever waits for a lower block id, so in-order dispatch cannot deadlock).  All four paths of a
-// pixel meet in one lane group: the cost is computed once and ONE summed byte per cell is stored.
-// D = 192 and byte-sized sums only (4 * (24 + P2max) <= 255).
-// ---------------------------------------------------------------------------------------
-struct SweepArgs {
-    const u8 *gray;
-    const u32 *cl;
-    const u32 *cr;
-    const u16 *p2lut;
-    u8 *s4;     // [B][Hp][Wp][192] sum of the pass's four paths
-    u32 *hand;  // [B][Hp/4][Wp][16 lanes][10 dwords]: NE, N, NW as bytes + their minima
-    int *prog;  // [B][Hp/4] pixels of the wave's last row that are published
-    int *err;   // set when a wait timed out
-    int B, Bpad, Hp, Wp, p1, mirror;
-};
-
-__device__ __forceinline__ u32 sw_ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void sw_st(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__global__ void __launch_bounds__(64) sweep4_kernel(SweepArgs a)
-{
-    constexpr int DPL = 12, NP = 6, D = 192;
-    __shared__ u16 s_lut[256];
-    for (int i = threadIdx.x; i < 256; i += 64) s_lut[i] = a.p2lut[i];
-    __syncthreads();
-    const int f = blockIdx.x % a.Bpad, k = blockIdx.x / a.Bpad;
-    if (f >= a.B) return;
-    const int lane = threadIdx.x, j = lane >> 4, l16 = lane & 15, dbase = DPL * l16;
-    const int Hp = a.Hp, Wp = a.Wp, nw = Hp / 4;
-    const int ys = 4 * k + j;                  // row in sweep space
-    const int y = a.mirror ? Hp - 1 - ys : ys; // row in the image
-    const int yu = a.mirror ? y + 1 : y - 1;   // image row of the sweep-space row above
-    const size_t fpix = (size_t)f * Hp * Wp;
-    const u8 *gray_f = a.gray + fpix;
-    const u32 *cl_f = a.cl + fpix, *cr_f = a.cr + fpix;
-    u8 *s4_f = a.s4 + fpix * D;
-    u32 *hand_out = a.hand + ((size_t)f * nw + k) * Wp * 160;
-    const u32 *hand_in = hand_out - (size_t)Wp * 160; // wave k-1 of the same frame
-    int *prog_out = a.prog + f * nw + k;
-    const int *prog_in = prog_out - 1;
-    const bool has_up_wave = k > 0;
-    const bool is_top = ys == 0;
-    const bool produce = (k + 1 < nw);
-    const u32 P1pk = pk_splat((u32)a.p1);
-    u32 inact[NP];
-    u32 LW[NP], oNE[NP], oN[NP], oNW[NP], dN[NP], dNW0[NP], dNW1[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) { inact[i] = 0; LW[i] = oNE[i] = oN[i] = oNW[i] = dN[i] = dNW0[i] = dNW1[i] = 0; }
-    u32 mW = 0, moNE = 0, moN = 0, moNW = 0, mdN = 0, mdNW0 = 0, mdNW1 = 0;
-    int prevI = 0, cached_prog = 0;
-    const int src_lane = ((lane - 16) & 63) << 2;
-    // step -1: the top group (xs = -1, not yet active) receives pixel 0 of the row above, which it needs as
-    // the N predecessor of its pixel 0
-    for (int s = -1; s < Wp + 6; s++) {
-        const int xs = s - 2 * j;
-        const bool active = xs >= 0 && xs < Wp;
-        const int xsc = xs < 0 ? 0 : (xs > Wp - 1 ? Wp - 1 : xs);
-        const int x = a.mirror ? Wp - 1 - xsc : xsc;
-        const int pix = y * Wp + x;
-        StepIn<DPL, false> in;
-        load_step<DPL, true, false>(in, gray_f, cl_f, cr_f, nullptr, pix, D, dbase, inact);
-        int Iup[3];
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            int xu = xsc + t - 1;
-            xu = xu < 0 ? 0 : (xu > Wp - 1 ? Wp - 1 : xu);
-            xu = a.mirror ? Wp - 1 - xu : xu;
-            Iup[t] = is_top ? 0 : (int)gray_f[yu * Wp + xu];
-        }
-        // ---- 1. what the group above produced in the previous step: pixel xs+1 of row ys-1 ----
-        u32 fNE[NP], fN[NP], fNW[NP], fmNE, fmN, fmNW;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            fNE[i] = (u32)__builtin_amdgcn_ds_bpermute(src_lane, (int)oNE[i]);
-            fN[i] = (u32)__builtin_amdgcn_ds_bpermute(src_lane, (int)oN[i]);
-            fNW[i] = (u32)__builtin_amdgcn_ds_bpermute(src_lane, (int)oNW[i]);
-        }
-        fmNE = (u32)__builtin_amdgcn_ds_bpermute(src_lane, (int)moNE);
-        fmN = (u32)__builtin_amdgcn_ds_bpermute(src_lane, (int)moN);
-        fmNW = (u32)__builtin_amdgcn_ds_bpermute(src_lane, (int)moNW);
-        const int xn = s + 1; // pixel of the upper wave's last row the top group needs now
-        if (has_up_wave && xn < Wp) { // wave-uniform
-            if (cached_prog < xn + 1) {
-                int spins = 0;
-                while (true) {
-                    cached_prog = __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cached_prog >= xn + 1) break;
-                    if (++spins > (1 << 22)) { *a.err = 1; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
-            if (j == 0) {
-                const u32 *rec = hand_in + ((size_t)xn * 16 + l16) * 10;
-                u32 r[10];
-#pragma unroll
-                for (int q = 0; q < 10; q++) r[q] = sw_ld(rec + q);
-#pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    // bytes 2i, 2i+1 of the 12-byte vector -> one u16 pair
-                    const u32 w0 = r[(2 * i) / 4], w1 = r[3 + (2 * i) / 4], w2 = r[6 + (2 * i) / 4];
-                    const u32 sel = ((2 * i) % 4 == 0) ? 0x0c010c00u : 0x0c030c02u;
-                    fNE[i] = __builtin_amdgcn_perm(w0, w0, sel);
-                    fN[i] = __builtin_amdgcn_perm(w1, w1, sel);
-                    fNW[i] = __builtin_amdgcn_perm(w2, w2, sel);
-                }
-                fmNE = pk_splat(r[9] & 0xFFu);
-                fmN = pk_splat((r[9] >> 8) & 0xFFu);
-                fmNW = pk_splat((r[9] >> 16) & 0xFFu);
-            }
-        }
-        // ---- 2. predecessors of this pixel (missing predecessor: zero vector, zero minimum => L = C) ----
-        const bool zW = xs <= 0, zN = is_top, zNW = is_top || xs <= 0, zNE = is_top || xs >= Wp - 1;
-        u32 vNW[NP], vN[NP], vNE[NP];
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            LW[i] = zW ? 0u : LW[i];
-            vNW[i] = zNW ? 0u : dNW1[i];
-            vN[i] = zN ? 0u : dN[i];
-            vNE[i] = zNE ? 0u : fNE[i];
-        }
-        mW = zW ? 0u : mW;
-        u32 mNW = zNW ? 0u : mdNW1, mN = zN ? 0u : mdN, mNE = zNE ? 0u : fmNE;
-        // ---- 3. matching costs, once for the four paths ----
-        u32 Cc[NP];
-        step_costs<DPL, false>(in, x - dbase, Cc);
-        // ---- 4. the four min-plus updates ----
-        int dW = in.I - prevI, dNWi = in.I - Iup[0], dNi = in.I - Iup[1], dNEi = in.I - Iup[2];
-        dW = dW < 0 ? -dW : dW; dNWi = dNWi < 0 ? -dNWi : dNWi; dNi = dNi < 0 ? -dNi : dNi; dNEi = dNEi < 0 ? -dNEi : dNEi;
-        sgm_update<NP, true, 16, false>(LW, Cc, Cc, Cc, P1pk, pk_splat(s_lut[dW]), mW, inact, false, false);
-        sgm_update<NP, true, 16, false>(vNW, Cc, Cc, Cc, P1pk, pk_splat(s_lut[dNWi]), mNW, inact, false, false);
-        sgm_update<NP, true, 16, false>(vN, Cc, Cc, Cc, P1pk, pk_splat(s_lut[dNi]), mN, inact, false, false);
-        sgm_update<NP, true, 16, false>(vNE, Cc, Cc, Cc, P1pk, pk_splat(s_lut[dNEi]), mNE, inact, false, false);
-        // ---- 5. one summed byte per cell ----
-        if (active) {
-            u32 sum[NP], bw[NP / 2];
-#pragma unroll
-            for (int i = 0; i < NP; i++) sum[i] = pk_adds(pk_adds(LW[i], vNW[i]), pk_adds(vN[i], vNE[i]));
-#pragma unroll
-            for (int i = 0; i + 1 < NP; i += 2) bw[i / 2] = __builtin_amdgcn_perm(sum[i + 1], sum[i], 0x06040200u);
-            store_words_nt<NP / 2>((u32 *)(s4_f + (size_t)((u32)pix * (u32)D + (u32)dbase)), bw);
-        }
-        // ---- 6. delay lines: N is needed one step after it arrives, NW two steps after ----
-#pragma unroll
-        for (int i = 0; i < NP; i++) { dNW1[i] = dNW0[i]; dNW0[i] = fNW[i]; dN[i] = fN[i]; }
-        mdNW1 = mdNW0; mdNW0 = fmNW; mdN = fmN;
-        // ---- 7. my outputs, for the group below in its next step ----
-#pragma unroll
-        for (int i = 0; i < NP; i++) { oNE[i] = vNE[i]; oN[i] = vN[i]; oNW[i] = vNW[i]; }
-        moNE = mNE; moN = mN; moNW = mNW;
-        // ---- 8. last row of the wave: publish for the wave below ----
-        if (produce) {
-            if (j == 3 && active) {
-                u32 *rec = hand_out + ((size_t)xs * 16 + l16) * 10;
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    sw_st(rec + q, __builtin_amdgcn_perm(vNE[2 * q + 1], vNE[2 * q], 0x06040200u));
-                    sw_st(rec + 3 + q, __builtin_amdgcn_perm(vN[2 * q + 1], vN[2 * q], 0x06040200u));
-                    sw_st(rec + 6 + q, __builtin_amdgcn_perm(vNW[2 * q + 1], vNW[2 * q], 0x06040200u));
-                }
-                sw_st(rec + 9, (mNE & 0xFFu) | ((mN & 0xFFu) << 8) | ((mNW & 0xFFu) << 16));
-            }
-            const int xl = s - 6; // pixel the last row has just finished
-            if (xl >= 0 && xl < Wp && ((xl & 7) == 7 || xl == Wp - 1)) { // wave-uniform
-                __builtin_amdgcn_s_waitcnt(0); // every store above has been acknowledged
-                if (lane == 63) __hip_atomic_store(prog_out, xl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        prevI = in.I;
-    }
-}
-
-// experiment launcher: s4 = sum of the four paths of pass `mirror` (0: W,NW,N,NE; 1: E,SE,S,SW)
-int rsgm_launch_sweep(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
-                      const u16 *p2lut, int p1, int mirror, u8 *s4, u32 *hand, int *prog, int *err)
-{
-    if (D != 192 || Hp % 4) { vppx_set_error("sweep experiment: D = 192 and Hp %% 4 == 0 only"); return VPPX_E_UNSUPPORTED; }
-    SweepArgs a;
-    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.s4 = s4; a.hand = hand; a.prog = prog; a.err = err;
-    a.B = B; a.Bpad = (B + 7) / 8 * 8; a.Hp = Hp; a.Wp = Wp; a.p1 = p1; a.mirror = mirror;
-    VPPX_HIP(hipMemsetAsync(prog, 0, (size_t)B * (Hp / 4) * sizeof(int), ctx->stream));
-    sweep4_kernel<<<dim3((unsigned)(a.Bpad * (Hp / 4))), 64, 0, ctx->stream>>>(a);
-    VPPX_CHECK_LAUNCH();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------
 // Vertical / diagonal paths by band marching (fast path of the fused pipeline).
 // Pass 0 walks the image top-down and carries N, NW, NE; pass 1 walks bottom-up and carries
 // S, SW, SE.  A workgroup owns VT = 64 columns and advances VR = 16 rows per launch; the three

@@ -991,65 +991,6 @@ extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t 
     return 0;
 }
 
-// experiment entry (not part of the drop-in surface): one pass of the raster-order four-path sweep on host
-// arrays; out = u8 [h][w][192] sum of W,NW,N,NE (mirror = 0) or E,SE,S,SW (mirror = 1).  ms_out: kernel time.
-extern "C" int vppx_debug_sweep(vppx_ctx *ctx, const uint8_t *img, const uint32_t *cl, const uint32_t *cr, int w, int h,
-                                int dmax, int p1, int p2min, float alpha, int gamma, int mirror, int batch_copies,
-                                uint8_t *out, float *ms_out)
-{
-    int rc;
-    if ((rc = check_ctx(ctx))) return rc;
-    if (!img || !cl || !cr || !out || w <= 0 || h <= 0 || batch_copies < 1) { vppx_set_error("vppx_debug_sweep: bad arguments"); return VPPX_E_INVALID_ARG; }
-    VppxRsgmParams p;
-    vppx_rsgm_params_default(&p);
-    p.dmax = dmax; p.p1 = p1; p.p2min = p2min; p.alpha = alpha; p.gamma = gamma;
-    u16 lut_h[256];
-    int maxp2;
-    p2_lut_host(p, lut_h, &maxp2);
-    if (4 * (24 + maxp2) > 255) { vppx_set_error("sweep experiment needs 4*(24+P2max) <= 255"); return VPPX_E_UNSUPPORTED; }
-    const int B = batch_copies;
-    const size_t n = (size_t)w * h;
-    u8 *dimg, *s4;
-    u32 *dcl, *dcr_raw, *hand;
-    u16 *lut_d;
-    int *prog, *err;
-    if ((rc = ws_get(ctx, WS_GRAY_L, n * B, &dimg))) return rc;
-    if ((rc = ws_get(ctx, WS_CENSUS_L, n * B, &dcl))) return rc;
-    if ((rc = ws_get(ctx, WS_CENSUS_R, n * B + 512, &dcr_raw))) return rc;
-    if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
-    if ((rc = ws_get(ctx, WS_PATHS, n * B * 192, &s4))) return rc;
-    if ((rc = ws_get(ctx, WS_SV, (size_t)B * (h / 4) * w * 160, &hand))) return rc;
-    if ((rc = ws_get(ctx, WS_VSTATE, (size_t)B * (h / 4) + 16, &prog))) return rc;
-    if ((rc = ws_get(ctx, WS_VMIN, (size_t)16, (u16 **)&err))) return rc;
-    u32 *dcr = dcr_raw + 512;
-    for (int b = 0; b < B; b++) {
-        VPPX_HIP(hipMemcpyAsync(dimg + b * n, img, n, hipMemcpyHostToDevice, ctx->stream));
-        VPPX_HIP(hipMemcpyAsync(dcl + b * n, cl, n * 4, hipMemcpyHostToDevice, ctx->stream));
-        VPPX_HIP(hipMemcpyAsync(dcr + b * n, cr, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-    VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));
-    ctx->lut_valid = false;
-    VPPX_HIP(hipMemsetAsync(err, 0, 16, ctx->stream));
-    hipEvent_t e0, e1;
-    VPPX_HIP(hipEventCreate(&e0));
-    VPPX_HIP(hipEventCreate(&e1));
-    if ((rc = rsgm_launch_sweep(ctx, B, h, w, dmax, dimg, dcl, dcr, lut_d, p1, mirror, s4, hand, prog, err))) return rc; // warm
-    VPPX_HIP(hipEventRecord(e0, ctx->stream));
-    if ((rc = rsgm_launch_sweep(ctx, B, h, w, dmax, dimg, dcl, dcr, lut_d, p1, mirror, s4, hand, prog, err))) return rc;
-    VPPX_HIP(hipEventRecord(e1, ctx->stream));
-    int herr = 0;
-    VPPX_HIP(hipMemcpyAsync(out, s4 + (size_t)(B - 1) * n * 192, n * 192, hipMemcpyDeviceToHost, ctx->stream));
-    VPPX_HIP(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    VPPX_HIP(hipStreamSynchronize(ctx->stream));
-    float ms = 0.f;
-    VPPX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    if (ms_out) *ms_out = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (herr) { vppx_set_error("sweep experiment: a hand-off wait timed out"); return VPPX_E_HIP; }
-    return 0;
-}
-
 static int wta_common(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, float uniqueness, int which)
 {
     int rc;

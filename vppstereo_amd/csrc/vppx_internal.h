@@ -208,9 +208,6 @@ size_t rsgm_vert_state_bytes(int B, int Wp, int D);
 size_t rsgm_vert_min_elems(int B, int Wp);
 int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u8 *gst, u16 *gmin);
-// experiment: raster-order sweep of four paths (see rsgm_kernels.hip)
-int rsgm_launch_sweep(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
-                      const u16 *p2lut, int p1, int mirror, u8 *s4, u32 *hand, int *prog, int *err);
 // S = sum of the 8 path volumes (+ left WTA, sub-pixel) ; disp_l may be null (stage API: S only)
 int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *paths, int elem_bytes, u16 *S,
                         u16 *ST, float *disp_l, u32 factor_uniq, int do_subpixel);
