@@ -1323,29 +1323,42 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     dim3 grid((g.W + 255) / 256, g.H, g.B);
     if ((rc = ws_get(ctx, WS_RCNT, npx, &k.rcnt))) return rc;
     if ((rc = ws_get(ctx, WS_RLIST, npx * RLCAP, &k.rlist))) return rc;
+    // The L side reads R only for occluded hints (pyx:114-122).  Without an occlusion mask the two sides are
+    // independent: the (latency-bound) L kernels then run on the side stream next to the R list build + replay.
+    const bool split = (occ == nullptr) && ctx->stream2 != nullptr;
+    hipStream_t ls = ctx->stream;
+    if (split) {
+        VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        ls = ctx->stream2;
+    }
     VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
     rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
     switch (k.n) { // sparse frames (each frame picks one of the two mappings on the device)
-    case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
-    case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
-    case 2: apply_l_hint_kernel<5><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
-    case 3: apply_l_hint_kernel<7><<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k); break;
+    case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
+    case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
+    case 2: apply_l_hint_kernel<5><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
+    case 3: apply_l_hint_kernel<7><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
     default: break;
     }
     VPPX_CHECK_LAUNCH();
     switch (k.n) {
-    case 0: apply_l_kernel<1><<<grid, 256, 0, ctx->stream>>>(k); break;
-    case 1: apply_l_kernel<3><<<grid, 256, 0, ctx->stream>>>(k); break;
-    case 2: apply_l_kernel<5><<<grid, 256, 0, ctx->stream>>>(k); break;
-    case 3: apply_l_kernel<7><<<grid, 256, 0, ctx->stream>>>(k); break;
-    default: apply_l_kernel<0><<<grid, 256, 0, ctx->stream>>>(k); break;
+    case 0: apply_l_kernel<1><<<grid, 256, 0, ls>>>(k); break;
+    case 1: apply_l_kernel<3><<<grid, 256, 0, ls>>>(k); break;
+    case 2: apply_l_kernel<5><<<grid, 256, 0, ls>>>(k); break;
+    case 3: apply_l_kernel<7><<<grid, 256, 0, ls>>>(k); break;
+    default: apply_l_kernel<0><<<grid, 256, 0, ls>>>(k); break;
     }
     VPPX_CHECK_LAUNCH();
     apply_r_hint_kernel<<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
     apply_r_kernel<<<grid, 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
+    if (split) {
+        VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
     stage_mark(ctx, ST_VPP_APPLY);
     return 0;
 }
