@@ -995,10 +995,10 @@ int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, i
     dim3 grid(nstrips, 2, B);
 #define LAUNCH_V(DPLV)                                                                                        \
     do {                                                                                                      \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) {                                                                                      \
+        static bool attr_set[VPPX_MAX_DEVICES] = {};                                                          \
+        if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)]) {                                                \
             VPPX_HIP(hipFuncSetAttribute((const void *)sgm_vert_kernel<DPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
-            attr_set = true;                                                                                  \
+            attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)] = true;                                            \
         }                                                                                                     \
         for (int band = 0; band < nbands; band++) {                                                           \
             a.band = band;                                                                                    \
@@ -1317,21 +1317,23 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
     constexpr int NR = (T + D - 2) / T + 1;
     constexpr int NT = NR + (SPARE ? 1 : 0);
     const size_t lds = (size_t)NT * D * (T + 2) * sizeof(u16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[VPPX_MAX_DEVICES] = {}; // function attributes are per device
+    const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
+    if (!attr_set[dv]) {
         VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dv] = true;
     }
     // one block per CU is resident (LDS): pick the rows-per-block split with the shortest makespan,
     // (waves of blocks over the CUs) x (rounds per block incl. its fill/drain rounds)
     static int forced = getenv("VPPX_SUM_BLOCKS") ? atoi(getenv("VPPX_SUM_BLOCKS")) : 0;
-    static int ncu = 0;
-    if (!ncu) {
+    static int ncu_of[VPPX_MAX_DEVICES] = {};
+    if (!ncu_of[dv]) {
         hipDeviceProp_t prop;
         VPPX_HIP(hipGetDeviceProperties(&prop, ctx->device));
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ncu_of[dv] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int ncu = ncu_of[dv];
     const int ntiles = (Wp + T - 1) / T;
     int chunks = 1;
     if (forced > 0) {

@@ -363,8 +363,8 @@ __global__ void __launch_bounds__(64) rand_full_kernel(int *__restrict__ out, lo
 // host-side tables: z^(b*LG) mod P (device resident, grown on demand) and z^N mod P
 static std::mutex g_tab_mutex;
 static std::vector<u32> g_tab_host; // [nblk][31]
-static u32 *g_tab_dev = nullptr;
-static int g_tab_dev_n = 0;
+static u32 *g_tab_dev[VPPX_MAX_DEVICES] = {}; // one copy per device a context lives on
+static int g_tab_dev_n[VPPX_MAX_DEVICES] = {};
 
 static void poly_pow_z(unsigned long long N, u32 *out)
 {
@@ -394,16 +394,17 @@ static int ensure_rand_table(vppx_ctx *ctx, int nblk, const u32 **tab_out)
         for (int b = (have == 0 ? 1 : have); b < nblk; b++)
             poly_mulmod(&g_tab_host[(size_t)(b - 1) * 31], step, &g_tab_host[(size_t)b * 31]);
     }
-    if (g_tab_dev_n < nblk) {
+    const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
+    if (g_tab_dev_n[dv] < nblk) {
         // grow: the old (shorter, prefix-identical) table is left alive on purpose -- kernels enqueued by other
         // contexts / streams and captured graphs may still reference it (a few MB per growth at most)
-        g_tab_dev = nullptr;
-        g_tab_dev_n = 0;
-        VPPX_HIP(hipMalloc((void **)&g_tab_dev, (size_t)nblk * 31 * sizeof(u32)));
-        VPPX_HIP(hipMemcpy(g_tab_dev, g_tab_host.data(), (size_t)nblk * 31 * sizeof(u32), hipMemcpyHostToDevice));
-        g_tab_dev_n = nblk;
+        g_tab_dev[dv] = nullptr;
+        g_tab_dev_n[dv] = 0;
+        VPPX_HIP(hipMalloc((void **)&g_tab_dev[dv], (size_t)nblk * 31 * sizeof(u32)));
+        VPPX_HIP(hipMemcpy(g_tab_dev[dv], g_tab_host.data(), (size_t)nblk * 31 * sizeof(u32), hipMemcpyHostToDevice));
+        g_tab_dev_n[dv] = nblk;
     }
-    *tab_out = g_tab_dev;
+    *tab_out = g_tab_dev[dv];
     return 0;
 }
 

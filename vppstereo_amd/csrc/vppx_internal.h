@@ -93,6 +93,7 @@ enum WsSlot {
 };
 
 #define VPPX_MAX_STAGES 24
+#define VPPX_MAX_DEVICES 64 // power of two: per-device one-time initialisations are indexed by device id
 
 struct vppx_ctx {
     int device = 0;
