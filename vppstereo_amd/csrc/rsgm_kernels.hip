@@ -1196,7 +1196,9 @@ struct VolPtrs {
 // A block walks `rows_per_block` consecutive rows as ONE stream of rounds (tile j of the stream is
 // tile j % ntiles of row j / ntiles): the operand prefetch and the right view's NR-1 round lag run
 // across row boundaries, so the fill/drain rounds are paid once per block instead of once per row.
-template <int DPL, typename IT, int NV, int T, bool SPARE>
+// SW4: byte volumes whose values are <= 63 (4 * max <= 255): four volumes are added as packed bytes with plain
+// 32-bit adds (no carry can cross a byte) before the sums are widened to u16 pairs
+template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4>
 __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
                                                           float *__restrict__ disp_r, int Hp, int Wp, u32 factor_uniq,
                                                           int do_subpixel, int rows_per_block)
@@ -1242,16 +1244,30 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
             u32 acc[NP];
 #pragma unroll
             for (int i = 0; i < NP; i++) acc[i] = 0;
+            if constexpr (SW4 && sizeof(IT) == 1 && (NV == 8 || NV == 4)) {
 #pragma unroll
-            for (int v = 0; v < NV; v++) {
-                if (sizeof(IT) == 2) {
+                for (int i = 0; i < NP / 2; i++) {
+                    const u32 ab = (w[0][i] + w[1][i]) + (w[2][i] + w[3][i]);
+                    acc[2 * i] = __builtin_amdgcn_perm(ab, ab, 0x0c010c00u);
+                    acc[2 * i + 1] = __builtin_amdgcn_perm(ab, ab, 0x0c030c02u);
+                    if constexpr (NV == 8) {
+                        const u32 cd = (w[4][i] + w[5][i]) + (w[6][i] + w[7][i]);
+                        acc[2 * i] = pk_adds(acc[2 * i], __builtin_amdgcn_perm(cd, cd, 0x0c010c00u));
+                        acc[2 * i + 1] = pk_adds(acc[2 * i + 1], __builtin_amdgcn_perm(cd, cd, 0x0c030c02u));
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], w[v][i]);
-                } else {
+                for (int v = 0; v < NV; v++) {
+                    if (sizeof(IT) == 2) {
 #pragma unroll
-                    for (int i = 0; i < NP / 2; i++) {
-                        acc[2 * i] = pk_adds(acc[2 * i], __builtin_amdgcn_perm(w[v][i], w[v][i], 0x0c010c00u));
-                        acc[2 * i + 1] = pk_adds(acc[2 * i + 1], __builtin_amdgcn_perm(w[v][i], w[v][i], 0x0c030c02u));
+                        for (int i = 0; i < NP; i++) acc[i] = pk_adds(acc[i], w[v][i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NP / 2; i++) {
+                            acc[2 * i] = pk_adds(acc[2 * i], __builtin_amdgcn_perm(w[v][i], w[v][i], 0x0c010c00u));
+                            acc[2 * i + 1] = pk_adds(acc[2 * i + 1], __builtin_amdgcn_perm(w[v][i], w[v][i], 0x0c030c02u));
+                        }
                     }
                 }
             }
@@ -1310,8 +1326,8 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
     }
 }
 
-template <int DPL, typename IT, int NV, int T, bool SPARE>
-static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
+template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4>
+static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
 {
     constexpr int D = 16 * DPL;
     constexpr int NR = (T + D - 2) / T + 1;
@@ -1320,7 +1336,7 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
     static bool attr_set[VPPX_MAX_DEVICES] = {}; // function attributes are per device
     const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
     if (!attr_set[dv]) {
-        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE>,
+        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dv] = true;
     }
@@ -1350,9 +1366,19 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
     }
     const int rpb = (Hp + chunks - 1) / chunks;
     chunks = (Hp + rpb - 1) / rpb;
-    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE><<<dim3(chunks, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
+    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4><<<dim3(chunks, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
     VPPX_CHECK_LAUNCH();
     return 0;
+}
+
+static bool g_sum_sw4 = false; // set per launch by rsgm_launch_sum_wta_lr (host-side dispatch only)
+template <int DPL, typename IT, int NV, int T, bool SPARE>
+static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
+{
+    if constexpr (sizeof(IT) == 1) {
+        if (g_sum_sw4) return launch_lr_t2<DPL, IT, NV, T, SPARE, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+    }
+    return launch_lr_t2<DPL, IT, NV, T, SPARE, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
 }
 
 template <typename IT, int NV>
@@ -1367,8 +1393,11 @@ static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
 }
 
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
-                           float *disp_l, float *disp_r, u32 fu, int sub)
+                           float *disp_l, float *disp_r, u32 fu, int sub, int max_path_value)
 {
+    // 8 single-path volumes: two groups of four are added as bytes; 4 volumes (band-marching variant): they hold
+    // sums of up to three paths, so all of them together must fit a byte
+    g_sum_sw4 = elem_bytes == 1 && max_path_value > 0 && (nvol == 8 ? 4 * max_path_value <= 255 : 8 * max_path_value <= 255);
     if ((D != 64 && D != 128 && D != 192 && D != 256) || (nvol != 8 && nvol != 4)) return 1; // caller falls back
     VolPtrs vp;
     for (int i = 0; i < 8; i++) vp.v[i] = i < nvol ? vols[i] : nullptr;

@@ -468,7 +468,8 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_DISP_R1, npp, &dr1))) return rc;
     const u32 fu = uniq_factor(p.uniqueness);
     // rsgm.py:141-142: matchWTA_SSE + subPixelRefine(.., 0) are always applied to the left map
-    rc = rsgm_launch_sum_wta_lr(ctx, g.B, g.Hp, g.Wp, g.D, vols, nvol, elem_bytes, dl0, dr0, fu, 1);
+    rc = rsgm_launch_sum_wta_lr(ctx, g.B, g.Hp, g.Wp, g.D, vols, nvol, elem_bytes, dl0, dr0, fu, 1,
+                                (hints && validhints) ? 0 : 24 + maxp2);
     if (rc < 0) return rc;
     if (rc == 0) {
         stage_mark(ctx, ST_SUM_WTA);

@@ -215,8 +215,9 @@ int rsgm_launch_sum_wta(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void 
 int rsgm_launch_wta_right_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *ST, float *disp, u32 factor_uniq);
 int rsgm_paths_elem_bytes(int D, int maxp2);
 // fused sum + left/right WTA; returns 1 (not an error) when the shape is not covered
+// max_path_value: upper bound of one path value (Cmax + P2max); 0 = unknown
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
-                           float *disp_l, float *disp_r, u32 factor_uniq, int do_subpixel);
+                           float *disp_l, float *disp_r, u32 factor_uniq, int do_subpixel, int max_path_value);
 int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
 int rsgm_launch_subpixel(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp);
 int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
