@@ -468,10 +468,14 @@ __device__ __forceinline__ void load_step(StepIn<DPL, FROM_DSI> &s, const u8 *gr
         }
         s.clv = 0;
     } else {
-        load_words<DPL>(cr_f + (pixl - dbase - (DPL - 1)), s.w); // w[j] = cr[x - (dbase + DPL-1-j)]
-        s.clv = cl_f[pixl];
+        // uniform base + 32-bit lane offset (scalar-base addressing, no 64-bit lane arithmetic); the base sits
+        // 512 words before the frame so that the offset of the first pixels (x - d < 0) stays non-negative
+        const u32 pb = (u32)pixl << 2;
+        const char *crb = (const char *)(cr_f - 512);
+        load_words<DPL>((const u32 *)(crb + (size_t)(pb + (u32)((512 - dbase - (DPL - 1)) * 4))), s.w); // w[j] = cr[x - (dbase + DPL-1-j)]
+        s.clv = *(const u32 *)((const char *)cl_f + (size_t)pb);
     }
-    s.I = gray_f[pixl];
+    s.I = gray_f[(size_t)(u32)pixl];
 }
 
 // packed matching costs of one step.  d > x has no right-image pixel: InvalidDispCost.
@@ -595,21 +599,30 @@ __device__ __forceinline__ void run_line(const u8 *gray_f, const u32 *cl_f, cons
     StepIn<DPL, FROM_DSI> A, Bq;
     load_step<DPL, EXACT, FROM_DSI>(A, gray_f, cl_f, cr_f, dsi_f, pix0, D, dbase, inact);
     st.prevI = A.I;
+    const int dpix = dys * Wp + dxs; // pixel index advance per step (before the diagonal wrap)
+    (void)y;
     for (int t = 0; t < nsteps; t += 2) {
-        // position of step t+1 (clamped at the end of the line: a harmless reload)
-        int x1 = x0 + dxs;
-        x1 = x1 >= Wp ? x1 - Wp : (x1 < 0 ? x1 + Wp : x1);
-        y += dys;
+        // position of step t+1 (clamped at the end of the line: a harmless reload).  Only diagonal lines can
+        // leave the image sideways: they wrap to the other border of the same row.
+        int x1 = x0 + dxs, p1 = pix0 + dpix;
+        if (DIAG) {
+            const int wr = x1 >= Wp ? -Wp : (x1 < 0 ? Wp : 0);
+            x1 += wr;
+            p1 += wr;
+        }
         const bool have1 = t + 1 < nsteps;
-        const int pix1 = have1 ? y * Wp + x1 : pix0;
+        const int pix1 = have1 ? p1 : pix0;
         load_step<DPL, EXACT, FROM_DSI>(Bq, gray_f, cl_f, cr_f, dsi_f, pix1, D, dbase, inact);
         line_step<DPL, EXACT, FROM_DSI, OT, DIAG, GW>(st, A, out_f, s_lut, x0, pix0, D, dbase, wrap_edge, P1pk, inact,
                                                       first, last, line_active);
         // position of step t+2
-        int x2 = x1 + dxs;
-        x2 = x2 >= Wp ? x2 - Wp : (x2 < 0 ? x2 + Wp : x2);
-        y += dys;
-        const int pix2 = (t + 2 < nsteps) ? y * Wp + x2 : pix1;
+        int x2 = x1 + dxs, p2 = pix1 + dpix;
+        if (DIAG) {
+            const int wr = x2 >= Wp ? -Wp : (x2 < 0 ? Wp : 0);
+            x2 += wr;
+            p2 += wr;
+        }
+        const int pix2 = (t + 2 < nsteps) ? p2 : pix1;
         load_step<DPL, EXACT, FROM_DSI>(A, gray_f, cl_f, cr_f, dsi_f, pix2, D, dbase, inact);
         if (have1)
             line_step<DPL, EXACT, FROM_DSI, OT, DIAG, GW>(st, Bq, out_f, s_lut, x1, pix1, D, dbase, wrap_edge, P1pk, inact,
