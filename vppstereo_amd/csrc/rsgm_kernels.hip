@@ -532,14 +532,14 @@ struct LineState {
 };
 
 template <int DPL, bool EXACT, bool FROM_DSI, typename OT, bool DIAG, int GW>
-__device__ __forceinline__ void line_step(LineState<DPL> &st, const StepIn<DPL, FROM_DSI> &in, OT *out_f, const u16 *s_lut,
+__device__ __forceinline__ void line_step(LineState<DPL> &st, const StepIn<DPL, FROM_DSI> &in, OT *out_f, const u32 *s_lut,
                                           int x, int pixl, int D, int dbase, int wrap_edge, u32 P1pk,
                                           const u32 (&inact)[DPL / 2], bool first, bool last, bool line_active)
 {
     constexpr int NP = DPL / 2;
-    int di = in.I - st.prevI;
-    di = di < 0 ? -di : di;
-    u32 P2pk = pk_splat(s_lut[di]);
+    // |I(p) - I(p-r)| of two bytes in one v_sad_u8; the table holds P2 already splatted into both halves
+    const u32 di = __builtin_amdgcn_sad_u8((u32)in.I, (u32)st.prevI, 0u);
+    u32 P2pk = s_lut[di];
     if (DIAG) {
         // chain restart at the image border (missing predecessor => L = C)
         const bool restart = (x == wrap_edge);
@@ -583,7 +583,7 @@ __device__ __forceinline__ void line_step(LineState<DPL> &st, const StepIn<DPL, 
 // step t+1 are in flight while step t computes, without register copies.
 template <int DPL, bool EXACT, bool FROM_DSI, typename OT, bool DIAG, int GW>
 __device__ __forceinline__ void run_line(const u8 *gray_f, const u32 *cl_f, const u32 *cr_f, const u16 *dsi_f, OT *out_f,
-                                         const u16 *s_lut, int Wp, int D, int x, int y, int dxs, int dys, int nsteps,
+                                         const u32 *s_lut, int Wp, int D, int x, int y, int dxs, int dys, int nsteps,
                                          int dbase, u32 P1pk, bool first, bool last, bool line_active)
 {
     constexpr int NP = DPL / 2;
@@ -636,8 +636,8 @@ template <int GW, int DPL, bool EXACT, bool FROM_DSI, typename OT>
 __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
 {
     constexpr int LPB = 256 / GW; // scan lines per block
-    __shared__ u16 s_lut[256];
-    s_lut[threadIdx.x] = a.p2lut[threadIdx.x];
+    __shared__ u32 s_lut[256];
+    s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
     __syncthreads();
 
     // blockIdx.x enumerates (line block, direction, frame).  When the batch is a multiple of 8
