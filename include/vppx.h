@@ -115,8 +115,12 @@ void vppx_rsgm_params_default(VppxRsgmParams *p);
  * process/GPU; not thread-safe (the reference is single-threaded: rsgm.py:44). */
 int vppx_create(vppx_ctx **out, int device);
 void vppx_destroy(vppx_ctx *ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+/* Use an existing hipStream_t (e.g. torch's current side stream); NULL = the context's own (non-blocking) stream.
+ * Binding the stream that is already bound costs nothing (no synchronisation). */
 int vppx_set_stream(vppx_ctx *ctx, void *hip_stream);
+/* Launch on the legacy default ("null") stream itself -- what torch's default stream is (its handle is 0, which
+ * vppx_set_stream reads as "own stream").  All work is then ordered with the caller's default-stream work. */
+int vppx_set_stream_legacy(vppx_ctx *ctx);
 int vppx_synchronize(vppx_ctx *ctx);
 /* Bytes of device workspace currently held by the context. */
 size_t vppx_workspace_bytes(const vppx_ctx *ctx);
@@ -127,6 +131,11 @@ const char *vppx_device_name(const vppx_ctx *ctx);
 /* init_rand(seed) (vpp_core_opt.pyx:33): restart the context's stream; subsequent
  * vppx_virtual_projection_scan_* calls continue it exactly like libc's global state. */
 int vppx_srand(vppx_ctx *ctx, uint32_t seed);
+/* Position of that stream: the seed of the last vppx_srand and the number of draws consumed since.  A batched
+ * caller (vpp_standalone.vpp through vppx_vpp_host) continues the stream by passing these as
+ * VppxVppParams.seed / .rand_offset and reporting what it consumed with vppx_rand_advance. */
+int vppx_rand_state(vppx_ctx *ctx, uint32_t *seed, uint64_t *consumed);
+int vppx_rand_advance(vppx_ctx *ctx, uint64_t draws);
 /* Device-generated glibc rand() stream: out[i] = i-th rand() after srand(seed), for
  * i in [offset, offset+n).  Host pointer. */
 int vppx_rand_stream(vppx_ctx *ctx, uint32_t seed, uint64_t offset, int64_t n, int32_t *out);

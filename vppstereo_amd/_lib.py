@@ -23,8 +23,8 @@ ERR_NAMES = {
 # every symbol include/vppx.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "vppx_version", "vppx_last_error", "vppx_vpp_params_default", "vppx_rsgm_params_default", "vppx_create",
-    "vppx_destroy", "vppx_set_stream", "vppx_synchronize", "vppx_workspace_bytes", "vppx_device_name", "vppx_srand",
-    "vppx_rand_stream", "vppx_virtual_projection_scan_rnd", "vppx_virtual_projection_scan_max_dist", "vppx_vpp_host",
+    "vppx_destroy", "vppx_set_stream", "vppx_set_stream_legacy", "vppx_synchronize", "vppx_workspace_bytes", "vppx_device_name", "vppx_srand",
+    "vppx_rand_stream", "vppx_rand_state", "vppx_rand_advance", "vppx_virtual_projection_scan_rnd", "vppx_virtual_projection_scan_max_dist", "vppx_vpp_host",
     "vppx_vpp_dev", "vppx_vpp_last_draws", "vppx_census5x5", "vppx_cost_census5x5_xyd", "vppx_aggregate", "vppx_match_wta",
     "vppx_match_wta_right", "vppx_subpixel_refine", "vppx_median3x3", "vppx_rsgm_host", "vppx_rsgm_dev",
     "vppx_vpp_rsgm_dev", "vppx_u8_to_nchw_dev", "vppx_psmnet_cost_volume_dev", "vppx_raft_corr_modulate_dev", "vppx_kitti_disp_decode_dev", "vppx_pfm_decode_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_set_graph_mode", "vppx_graph_replays", "vppx_time_aggregate", "vppx_agg_kernel_ms", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert",
@@ -94,8 +94,11 @@ def load():
         lib.vppx_destroy.argtypes = [vp]
         lib.vppx_destroy.restype = None
         lib.vppx_set_stream.argtypes = [vp, vp]
+        lib.vppx_set_stream_legacy.argtypes = [vp]
         lib.vppx_synchronize.argtypes = [vp]
         lib.vppx_srand.argtypes = [vp, C.c_uint32]
+        lib.vppx_rand_state.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        lib.vppx_rand_advance.argtypes = [vp, C.c_uint64]
         lib.vppx_rand_stream.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_int64, vp]
         i, f, d = C.c_int, C.c_float, C.c_double
         lib.vppx_virtual_projection_scan_rnd.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, f, f, vp, i, i]
@@ -175,7 +178,15 @@ class Context:
             pass
 
     def set_stream(self, stream_ptr):
-        check(self._lib.vppx_set_stream(self._h, C.c_void_p(stream_ptr)))
+        """Bind a hipStream_t handle; 0 / None = the legacy default stream (torch's default stream)."""
+        if not stream_ptr:
+            check(self._lib.vppx_set_stream_legacy(self._h))
+        else:
+            check(self._lib.vppx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def use_own_stream(self):
+        """Back to the context's private non-blocking stream (what a fresh context uses)."""
+        check(self._lib.vppx_set_stream(self._h, None))
 
     def synchronize(self):
         check(self._lib.vppx_synchronize(self._h))
@@ -210,20 +221,27 @@ def default_context():
     return _default_ctx
 
 
+def _fill(p, kw):
+    # setattr on a ctypes.Structure silently creates a Python attribute for an unknown name: a misspelt or
+    # reference-style keyword (blending=, wsizeAgg_x=) must not be ignored
+    names = {f[0] for f in p._fields_ if not f[0].startswith("reserved")}
+    for k, v in kw.items():
+        if k not in names:
+            raise TypeError(f"{type(p).__name__}: unknown parameter {k!r} (fields: {sorted(names)})")
+        setattr(p, k, v)
+    return p
+
+
 def vpp_params(**kw):
     p = VppxVppParams()
     load().vppx_vpp_params_default(C.byref(p))
-    for k, v in kw.items():
-        setattr(p, k, v)
-    return p
+    return _fill(p, kw)
 
 
 def rsgm_params(**kw):
     p = VppxRsgmParams()
     load().vppx_rsgm_params_default(C.byref(p))
-    for k, v in kw.items():
-        setattr(p, k, v)
-    return p
+    return _fill(p, kw)
 
 
 def c_contig(a, dtype):

@@ -24,6 +24,25 @@ void vppx_set_error(const char *fmt, ...)
 extern "C" const char *vppx_last_error(void) { return g_err; }
 extern "C" int vppx_version(void) { return VPPX_VERSION; }
 
+// Every entry point runs with the context's device current and puts the caller's device back on return
+// (a torch process may hold contexts on several GPUs; the library must not change its current device).
+struct DevGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DevGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) changed = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DevGuard()
+    {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define VPPX_ENTER(ctx)                                                                                              \
+    if (!(ctx)) { vppx_set_error("context is NULL (vppx_create failed? there is no CPU fallback)"); return VPPX_E_NO_DEVICE; } \
+    DevGuard dev_guard_((ctx)->device)
+
 extern "C" void vppx_vpp_params_default(VppxVppParams *p)
 {
     memset(p, 0, sizeof(*p));
@@ -103,7 +122,7 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (hipGetDevice(&device) != hipSuccess) device = 0;
     }
     if (device >= ndev) { vppx_set_error("device %d out of range (%d devices)", device, ndev); return VPPX_E_INVALID_ARG; }
-    VPPX_HIP(hipSetDevice(device));
+    DevGuard dev_guard_(device); // the caller's current device is restored on return
     vppx_ctx *ctx = new vppx_ctx();
     ctx->device = device;
     hipDeviceProp_t prop;
@@ -144,7 +163,7 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
 extern "C" void vppx_destroy(vppx_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DevGuard dev_guard_(ctx->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 4; i++) {
         if (ctx->sub[i]) vppx_destroy(ctx->sub[i]);
@@ -176,28 +195,51 @@ extern "C" int vppx_set_graph_mode(vppx_ctx *ctx, int enable)
 
 extern "C" long vppx_graph_replays(vppx_ctx *ctx) { return ctx ? ctx->graph_replays : 0; }
 
-extern "C" int vppx_set_stream(vppx_ctx *ctx, void *hip_stream)
+// Drop the context's own stream (after draining it) before it is pointed at a caller's stream.
+static int release_own_stream(vppx_ctx *ctx)
 {
-    if (!ctx) return VPPX_E_INVALID_ARG;
     if (ctx->own_stream && ctx->stream) {
         VPPX_HIP(hipStreamSynchronize(ctx->stream));
-        if (hip_stream != nullptr) {
-            (void)hipStreamDestroy(ctx->stream);
-            ctx->own_stream = false;
-        }
+        (void)hipStreamDestroy(ctx->stream);
     }
+    ctx->own_stream = false;
+    ctx->stream = nullptr;
+    return 0;
+}
+
+extern "C" int vppx_set_stream(vppx_ctx *ctx, void *hip_stream)
+{
+    VPPX_ENTER(ctx);
     if (hip_stream != nullptr) {
+        if (ctx->stream == (hipStream_t)hip_stream && !ctx->own_stream && !ctx->legacy_stream) return 0; // already bound
+        int rc = release_own_stream(ctx);
+        if (rc) return rc;
         ctx->stream = (hipStream_t)hip_stream;
+        ctx->legacy_stream = false;
     } else if (!ctx->own_stream) {
         VPPX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
+        ctx->legacy_stream = false;
     }
+    return 0;
+}
+
+// Launch on the legacy default ("null") stream itself: what torch's default stream is.  Work is then ordered
+// with everything else the process enqueues there, exactly like kernels torch launches on its default stream.
+extern "C" int vppx_set_stream_legacy(vppx_ctx *ctx)
+{
+    VPPX_ENTER(ctx);
+    if (ctx->legacy_stream) return 0;
+    int rc = release_own_stream(ctx);
+    if (rc) return rc;
+    ctx->stream = nullptr; // hipStream_t 0 = the legacy default stream
+    ctx->legacy_stream = true;
     return 0;
 }
 
 extern "C" int vppx_synchronize(vppx_ctx *ctx)
 {
-    if (!ctx) return VPPX_E_INVALID_ARG;
+    VPPX_ENTER(ctx);
     VPPX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -264,13 +306,6 @@ extern "C" int vppx_get_stage_ms(vppx_ctx *ctx, float *ms, int max_n)
 // ---------------------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------------------
-static int check_ctx(vppx_ctx *ctx)
-{
-    if (!ctx) { vppx_set_error("context is NULL (vppx_create failed? there is no CPU fallback)"); return VPPX_E_NO_DEVICE; }
-    VPPX_HIP(hipSetDevice(ctx->device));
-    return 0;
-}
-
 static int upload(vppx_ctx *ctx, WsSlot s, const void *host, size_t bytes, void **dev)
 {
     int rc = ws_reserve(ctx, s, bytes, dev);
@@ -512,7 +547,7 @@ extern "C" int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int 
                              const float *validhints, float *disp_out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!p || !left || !left_vpp || !right_vpp || !disp_out) { vppx_set_error("vppx_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_frames(B, H, W, C))) return rc;
     if ((rc = check_rsgm_params(*p))) return rc;
@@ -528,7 +563,7 @@ extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int
                               const float *validhints, float *disp_out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!p || !left || !left_vpp || !right_vpp || !disp_out) { vppx_set_error("vppx_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_frames(B, H, W, C))) return rc;
     const size_t nb = (size_t)B * H * W * C;
@@ -564,7 +599,7 @@ extern "C" int vppx_vpp_dev(vppx_ctx *ctx, const VppxVppParams *p, int B, int H,
                             const float *g, const uint8_t *g_occ, const float *filled_g, int64_t *n_hints_dev)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!p || !l || !r || !g) { vppx_set_error("vppx_vpp: NULL argument"); return VPPX_E_INVALID_ARG; }
     if (B <= 0 || H <= 0 || W <= 0) { vppx_set_error("bad shape B=%d H=%d W=%d", B, H, W); return VPPX_E_INVALID_ARG; }
     if ((rc = check_vpp_params(*p))) return rc;
@@ -583,7 +618,7 @@ extern "C" int vppx_vpp_host(vppx_ctx *ctx, const VppxVppParams *p, int B, int H
                              const float *g, const uint8_t *g_occ, const float *filled_g, int64_t *n_hints)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!p || !l || !r || !g) { vppx_set_error("vppx_vpp: NULL argument"); return VPPX_E_INVALID_ARG; }
     if (B <= 0 || H <= 0 || W <= 0) { vppx_set_error("bad shape B=%d H=%d W=%d", B, H, W); return VPPX_E_INVALID_ARG; }
     const size_t nb = (size_t)B * H * W * C, np = (size_t)B * H * W;
@@ -607,7 +642,7 @@ extern "C" int vppx_vpp_host(vppx_ctx *ctx, const VppxVppParams *p, int B, int H
 extern "C" int vppx_vpp_last_draws(vppx_ctx *ctx, int B, uint64_t *draws)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!draws || B <= 0 || !ctx->ws[WS_FRAME_TOT].p || ctx->ws[WS_FRAME_TOT].cap < (size_t)B * 16) {
         vppx_set_error("vppx_vpp_last_draws: no VPP call with B >= %d has run", B);
         return VPPX_E_INVALID_ARG;
@@ -627,12 +662,28 @@ extern "C" int vppx_srand(vppx_ctx *ctx, uint32_t seed)
     return 0;
 }
 
+// the context's libc-like stream position (what libc keeps in its global rand() state)
+extern "C" int vppx_rand_state(vppx_ctx *ctx, uint32_t *seed, uint64_t *consumed)
+{
+    if (!ctx) { vppx_set_error("context is NULL"); return VPPX_E_NO_DEVICE; }
+    if (seed) *seed = ctx->rnd_seed;
+    if (consumed) *consumed = ctx->rnd_consumed;
+    return 0;
+}
+
+extern "C" int vppx_rand_advance(vppx_ctx *ctx, uint64_t draws)
+{
+    if (!ctx) { vppx_set_error("context is NULL"); return VPPX_E_NO_DEVICE; }
+    ctx->rnd_consumed += draws;
+    return 0;
+}
+
 // number of rand() draws a scan consumed = what the device prefix sums computed
 static int scan_common(vppx_ctx *ctx, VppxVppParams &p, uint8_t *l, uint8_t *r, const float *g, int width, int height,
                        int channels, const uint8_t *g_occ)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     p.seed = ctx->rnd_seed;
     p.rand_offset = ctx->rnd_consumed;
     int64_t nh = 0;
@@ -676,7 +727,7 @@ extern "C" int vppx_virtual_projection_scan_max_dist(vppx_ctx *ctx, uint8_t *l, 
 extern "C" int vppx_rand_stream(vppx_ctx *ctx, uint32_t seed, uint64_t offset, int64_t n, int32_t *out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (n < 0 || (n > 0 && !out)) { vppx_set_error("vppx_rand_stream: bad arguments"); return VPPX_E_INVALID_ARG; }
     if (n == 0) return 0;
     void *d;
@@ -721,7 +772,7 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
                                  uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!vp || !rp || !left || !right || !g || !disp_out) { vppx_set_error("vppx_vpp_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_frames(B, H, W, C))) return rc;
     if ((rc = check_vpp_params(*vp))) return rc;
@@ -822,7 +873,7 @@ extern "C" int vppx_u8_to_nchw_dev(vppx_ctx *ctx, int B, int H, int W, int C, in
                                    void *dst, int dst_is_bf16)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad_multiple <= 0) { vppx_set_error("vppx_u8_to_nchw: bad arguments"); return VPPX_E_INVALID_ARG; }
     return rsgm_launch_to_nchw(ctx, B, H, W, C, pad_multiple, src, dst, dst_is_bf16 != 0);
 }
@@ -835,7 +886,7 @@ extern "C" int vppx_psmnet_cost_volume_dev(vppx_ctx *ctx, const float *fea_l, co
                                            int maxdisp, float *cost)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!fea_l || !fea_r || !cost || B <= 0 || C <= 0 || H4 <= 0 || W4 <= 0 || maxdisp < 4 || (hints && !validhints)) {
         vppx_set_error("vppx_psmnet_cost_volume: bad arguments");
         return VPPX_E_INVALID_ARG;
@@ -847,7 +898,7 @@ extern "C" int vppx_raft_corr_modulate_dev(vppx_ctx *ctx, float *corr, const flo
                                            int H4, int W2, int W3, int H, int W)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!corr || !hints || !validhints || B <= 0 || H4 <= 0 || W2 <= 0 || W3 <= 0) {
         vppx_set_error("vppx_raft_corr_modulate: bad arguments");
         return VPPX_E_INVALID_ARG;
@@ -858,7 +909,7 @@ extern "C" int vppx_raft_corr_modulate_dev(vppx_ctx *ctx, float *corr, const flo
 extern "C" int vppx_kitti_disp_decode_dev(vppx_ctx *ctx, const uint16_t *png_u16, int64_t n, float *disp, uint8_t *valid)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!png_u16 || !disp || n < 0) { vppx_set_error("vppx_kitti_disp_decode: bad arguments"); return VPPX_E_INVALID_ARG; }
     if (n == 0) return 0;
     return handoff_kitti_decode(ctx, png_u16, (size_t)n, disp, valid);
@@ -868,7 +919,7 @@ extern "C" int vppx_pfm_decode_dev(vppx_ctx *ctx, const uint8_t *raw, int H, int
                                    float *out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!raw || !out || H <= 0 || W <= 0 || (channels != 1 && channels != 3) || ((uintptr_t)raw & 3)) {
         vppx_set_error("vppx_pfm_decode: bad arguments (channels must be 1 or 3, payload 4-byte aligned)");
         return VPPX_E_INVALID_ARG;
@@ -883,7 +934,7 @@ extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, 
                                             double l, double g, double th_conf, double th_filter, uint8_t *conf_out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
     const size_t n = (size_t)B * H * W;
     float *omap;
@@ -897,7 +948,7 @@ extern "C" int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W,
                                              double l, double g, double th_conf, double th_filter, uint8_t *conf_out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
     const size_t n = (size_t)B * H * W;
     void *dh, *dc;
@@ -928,7 +979,7 @@ static int check_dmax(int dmax)
 extern "C" int vppx_census5x5(vppx_ctx *ctx, const uint8_t *img, uint32_t *out, int w, int h)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!img || !out || w <= 0 || h <= 0) { vppx_set_error("vppx_census5x5: bad arguments"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_w16(w))) return rc;
     const size_t n = (size_t)w * h;
@@ -946,7 +997,7 @@ extern "C" int vppx_cost_census5x5_xyd(vppx_ctx *ctx, const uint32_t *cl, const 
 {
     (void)n_threads_ignored;
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!cl || !cr || !dsi || w <= 0 || h <= 0) { vppx_set_error("vppx_cost: bad arguments"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_dmax(dmax))) return rc;
     if ((rc = check_w16(w))) return rc;
@@ -965,7 +1016,7 @@ extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t 
                               int dmax, int p1, int p2min, float alpha, int gamma)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!img || !dsi || !dsi_agg || w <= 0 || h <= 0) { vppx_set_error("vppx_aggregate: bad arguments"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_w16(w))) return rc; // rsgm.py:51-58 order
     if ((rc = check_dmax(dmax))) return rc;
@@ -995,7 +1046,7 @@ extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t 
 static int wta_common(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, float uniqueness, int which)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!dsi || !disp || w <= 0 || h <= 0) { vppx_set_error("vppx_match_wta: bad arguments"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_w16(w))) return rc;
     if ((rc = check_dmax(dmax))) return rc;
@@ -1038,7 +1089,7 @@ extern "C" int vppx_subpixel_refine(vppx_ctx *ctx, const uint16_t *dsi, float *d
 extern "C" int vppx_median3x3(vppx_ctx *ctx, const float *src, float *dst, int w, int h)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!src || !dst || w <= 0 || h <= 0) { vppx_set_error("vppx_median3x3: bad arguments"); return VPPX_E_INVALID_ARG; }
     const size_t n = (size_t)w * h;
     void *ds, *dd;
@@ -1056,7 +1107,7 @@ extern "C" int vppx_median3x3(vppx_ctx *ctx, const float *src, float *dst, int w
 static int time_aggregation(vppx_ctx *ctx, int iters, int which, float *ms_out)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (!ctx->have_last && ctx->sub[0] && ctx->sub[0]->have_last) ctx = ctx->sub[0]; // batch was split: time one part
     if (!ctx->have_last || iters <= 0 || !ms_out) { vppx_set_error("vppx_time_aggregate: call vppx_rsgm_dev first"); return VPPX_E_INVALID_ARG; }
     const VppxRsgmParams &p = ctx->last_rp;
@@ -1102,7 +1153,7 @@ extern "C" int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, floa
 extern "C" int vppx_agg_kernel_ms(vppx_ctx *ctx, int last_n, float *avg_ms, int *n_used)
 {
     int rc;
-    if ((rc = check_ctx(ctx))) return rc;
+    VPPX_ENTER(ctx);
     if (ctx->nsub > 1 && ctx->sub[0]) ctx = ctx->sub[0]; // split batch: one part's launches
     if (last_n <= 0) { ctx->agg_calls = 0; if (n_used) *n_used = 0; if (avg_ms) *avg_ms = 0.f; return 0; }
     if (!avg_ms) return VPPX_E_INVALID_ARG;

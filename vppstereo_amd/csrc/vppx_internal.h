@@ -99,6 +99,7 @@ struct vppx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool legacy_stream = false;    // launches go to the legacy default (null) stream: vppx_set_stream_legacy
     hipStream_t stream2 = nullptr; // side stream: horizontal paths overlap the vertical band launches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // sub-contexts: the fused batched call splits its frames over `nsub` child contexts (own stream

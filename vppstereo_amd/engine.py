@@ -28,19 +28,33 @@ class Engine:
         self.lib = _lib.load()
 
     def _bind_stream(self):
+        """Run on torch's current stream, so that library kernels are ordered with the torch work around them.
+        torch's default stream is the legacy null stream (handle 0): the context then launches on the null stream
+        itself (vppx_set_stream_legacy); re-binding an unchanged stream costs nothing."""
         self.ctx.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _chk(self, t, dtype, ndim, name):
-        torch = self.torch
+    def _chk(self, t, dtype, ndim, name, shape=None):
+        """Every tensor handed to the C-ABI is checked here: the library trusts B/H/W/C and raw pointers."""
         if t.device != self.device or t.dtype != dtype or t.dim() != ndim or not t.is_contiguous():
             raise ValueError(f"{name}: expected contiguous {dtype} tensor with {ndim} dims on {self.device}")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+    def _chk_pair(self, left, right, hints, g_occ=None):
+        torch = self.torch
+        self._chk(left, torch.uint8, 4, "left")
+        B, H, W, Cc = left.shape
+        if Cc not in (1, 3):
+            raise ValueError("left: channels must be 1 or 3")
+        self._chk(right, torch.uint8, 4, "right", left.shape)
+        self._chk(hints, torch.float32, 3, "hints", (B, H, W))
+        if g_occ is not None:
+            self._chk(g_occ, torch.uint8, 3, "g_occ", (B, H, W))
+        return B, H, W, Cc
 
     def vpp(self, left, right, hints, g_occ=None, seed=1, **kw):
         """In-place-free VPP: returns patterned copies (l_vpp, r_vpp) like vpp() does."""
-        torch = self.torch
-        self._chk(left, torch.uint8, 4, "left"); self._chk(right, torch.uint8, 4, "right")
-        self._chk(hints, torch.float32, 3, "hints")
-        B, H, W, Cc = left.shape
+        B, H, W, Cc = self._chk_pair(left, right, hints, g_occ)
         self._bind_stream()
         l, r = left.clone(), right.clone()
         p = _lib.vpp_params(seed=int(seed) & 0xFFFFFFFF, **kw)
@@ -50,11 +64,13 @@ class Engine:
 
     def rsgm(self, left, left_vpp, right_vpp, out=None, **kw):
         torch = self.torch
-        for t, n in ((left, "left"), (left_vpp, "left_vpp"), (right_vpp, "right_vpp")):
-            self._chk(t, torch.uint8, 4, n)
+        self._chk(left, torch.uint8, 4, "left")
         B, H, W, Cc = left.shape
+        self._chk(left_vpp, torch.uint8, 4, "left_vpp", left.shape)
+        self._chk(right_vpp, torch.uint8, 4, "right_vpp", left.shape)
         if out is None:
             out = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
+        self._chk(out, torch.float32, 3, "out", (B, H, W))
         self._bind_stream()
         p = _lib.rsgm_params(**kw)
         _lib.check(self.lib.vppx_rsgm_dev(self.ctx.handle, C.byref(p), B, H, W, Cc, _ptr(left), _ptr(left_vpp),
@@ -65,11 +81,13 @@ class Engine:
                  rsgm_kw=None):
         """The whole hot path for a batch: one call, no host round trips, no synchronisation."""
         torch = self.torch
-        self._chk(left, torch.uint8, 4, "left"); self._chk(right, torch.uint8, 4, "right")
-        self._chk(hints, torch.float32, 3, "hints")
-        B, H, W, Cc = left.shape
+        B, H, W, Cc = self._chk_pair(left, right, hints, g_occ)
         if out is None:
             out = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
+        self._chk(out, torch.float32, 3, "out", (B, H, W))
+        for t, n in ((l_vpp, "l_vpp"), (r_vpp, "r_vpp")):
+            if t is not None:
+                self._chk(t, torch.uint8, 4, n, left.shape)
         self._bind_stream()
         vp = _lib.vpp_params(seed=int(seed) & 0xFFFFFFFF, **(vpp_kw or {}))
         rp = _lib.rsgm_params(**(rsgm_kw or {}))

@@ -27,7 +27,7 @@ def vpp(left, right, gt, wsize=3, wsizeAgg_x=64, wsizeAgg_y=3, left2right=True, 
         return lc, rc
 
     pos = gt[gt > 0]
-    dmin, dmax = (float(pos.min()), float(pos.max())) if pos.size else (0.0, 0.0)   # :410-411
+    dmin, dmax = float(pos.min()), float(pos.max())   # :410-411 (ValueError on non-zero hints that are all <= 0, as there)
     if use_distance_patch and not dmax > dmin:
         raise ZeroDivisionError("use_distance_patch needs two distinct hint values "
                                 "(vpp_standalone.py:8 divides by dmax-dmin)")
@@ -48,25 +48,24 @@ def vpp(left, right, gt, wsize=3, wsizeAgg_x=64, wsizeAgg_y=3, left2right=True, 
                         distance_gamma=float(distance_gamma), dmin=dmin, dmax=dmax,
                         use_bilateral_patch=int(bool(use_bilateral_patch)), bilateral_o_xy=float(bilateral_o_xy),
                         bilateral_o_i=float(bilateral_o_i), bilateral_th=float(bilateral_th))
-    # continue the libc-like stream shared with vpp_core_opt.init_rand (global state in the reference)
-    p.seed = _stream["seed"]
-    p.rand_offset = _stream["consumed"]
+    # continue the libc-like stream of the default context: the SAME (seed, draws consumed) state that
+    # vpp_core_opt.init_rand seeds and the single-frame scans advance (global libc state in the reference)
+    seed, consumed = C.c_uint32(), C.c_uint64()
+    _lib.check(lib.vppx_rand_state(ctx.handle, C.byref(seed), C.byref(consumed)))
+    p.seed = seed.value
+    p.rand_offset = consumed.value
     nh = (C.c_int64 * 1)()
     _lib.check(lib.vppx_vpp_host(ctx.handle, C.byref(p), 1, h, w, ch, _lib.np_ptr(lc), _lib.np_ptr(rc),
                                  _lib.np_ptr(gt), _lib.np_ptr(occ), None, nh))
     if method == "rnd":  # maxDistance draws nothing from rand()
         draws = (C.c_uint64 * 1)()
         _lib.check(lib.vppx_vpp_last_draws(ctx.handle, 1, draws))
-        _stream["consumed"] += int(draws[0])
+        _lib.check(lib.vppx_rand_advance(ctx.handle, int(draws[0])))
     return lc, rc
 
 
-# vpp() keeps its own (seed, draws consumed) position so that successive calls continue one
-# glibc stream, as the reference's scans do with libc's global rand() state.
-_stream = {"seed": 1, "consumed": 0}
-
-
 def init_rand(seed=0):
-    """Re-seed the stream used by vpp() (the reference seeds libc via vpp_core_opt.init_rand)."""
-    _stream["seed"] = int(seed) & 0xFFFFFFFF
-    _stream["consumed"] = 0
+    """Re-seed the stream used by vpp() and by the vpp_core_opt scans (one state, like libc's): same as
+    vpp_core_opt.init_rand."""
+    from . import vpp_core_opt
+    vpp_core_opt.init_rand(seed)
