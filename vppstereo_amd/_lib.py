@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvppx.so")
+LIB_PATH = os.environ.get("VPPX_LIB") or os.path.join(_HERE, "libvppx.so")  # VPPX_LIB: experiment builds
 
 VPPX_OK = 0
 ERR_NAMES = {

@@ -400,7 +400,10 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], con
         left_in = first ? 0xFFFFFFFFu : left_in;
         right_in = last ? 0xFFFFFFFFu : right_in;
     }
-    const u32 t2 = pk_adds(minpk, P2pk);
+    // FUSE = byte volumes: every value stays far below 2^16, so the packed adds / subtracts cannot carry or borrow
+    // across the halves and plain 32-bit v_add_u32 / v_sub_u32 do the same job at twice the issue rate of the
+    // VOP3P forms on gfx950 (tools/valu_bench.hip: 2 vs 4 cycles per wave-instruction)
+    const u32 t2 = FUSE ? minpk + P2pk : pk_adds(minpk, P2pk);
     u32 al[NP + 1]; // al[i] = {L[2i-1], L[2i]}
     al[0] = __builtin_amdgcn_alignbit(L[0], left_in, 16);
 #pragma unroll
@@ -410,7 +413,7 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], con
 #pragma unroll
     for (int i = 0; i < NP; i++) m[i] = pk_min(al[i], al[i + 1]);
 #pragma unroll
-    for (int i = 0; i < NP; i++) m[i] = pk_adds(m[i], P1pk);
+    for (int i = 0; i < NP; i++) m[i] = FUSE ? m[i] + P1pk : pk_adds(m[i], P1pk);
 #pragma unroll
     for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], L[i]);
 #pragma unroll
@@ -430,7 +433,7 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], con
     }
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        m[i] = pk_sub(m[i], minpk);
+        m[i] = FUSE ? m[i] - minpk : pk_sub(m[i], minpk);
         if (!EXACT) m[i] |= inact[i]; // slots d >= D stay at the 0xFFFF sentinel (never the minimum)
         L[i] = m[i];
     }
@@ -574,7 +577,11 @@ __device__ __forceinline__ void line_step(LineState<DPL> &st, const StepIn<DPL, 
         step_costs<DPL, FROM_DSI>(in, FROM_DSI ? DPL : lim, C);
         sgm_update<NP, EXACT, GW, false>(st.L, C, C, C, P1pk, P2pk, st.minpk, inact, first, last);
     }
-    if (line_active) store_step<DPL, EXACT, OT>(out_f, pixl, D, dbase, st.L, inact);
+    // No branch around the store in the fast variant: a store inside a conditional block makes hipcc's s_waitcnt
+    // bookkeeping assume the smaller number of younger operations, so every wait for a prefetched load also drained
+    // the stores issued after it (vmcnt(0) on the loop back edge: the wave idled for a store round trip per step).
+    // The lanes of a clamped, inactive line hold exactly the values of the last line and may store them again.
+    if (CAN_FUSE || line_active) store_step<DPL, EXACT, OT>(out_f, pixl, D, dbase, st.L, inact);
     st.prevI = in.I;
 }
 
@@ -610,7 +617,9 @@ __device__ __forceinline__ void run_line(const u8 *gray_f, const u32 *cl_f, cons
             x1 += wr;
             p1 += wr;
         }
-        const bool have1 = t + 1 < nsteps;
+        // the fast variant only sees padded frames (Hp, Wp multiples of 16): an even number of steps, no tail branch
+        constexpr bool EVEN = !FROM_DSI && EXACT && sizeof(OT) == 1;
+        const bool have1 = EVEN || (t + 1 < nsteps);
         const int pix1 = have1 ? p1 : pix0;
         load_step<DPL, EXACT, FROM_DSI>(Bq, gray_f, cl_f, cr_f, dsi_f, pix1, D, dbase, inact);
         line_step<DPL, EXACT, FROM_DSI, OT, DIAG, GW>(st, A, out_f, s_lut, x0, pix0, D, dbase, wrap_edge, P1pk, inact,
@@ -1384,25 +1393,25 @@ static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp,
     return 0;
 }
 
-static bool g_sum_sw4 = false; // set per launch by rsgm_launch_sum_wta_lr (host-side dispatch only)
 template <int DPL, typename IT, int NV, int T, bool SPARE>
-static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
+static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub,
+                       bool sw4)
 {
     if constexpr (sizeof(IT) == 1) {
-        if (g_sum_sw4) return launch_lr_t2<DPL, IT, NV, T, SPARE, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+        if (sw4) return launch_lr_t2<DPL, IT, NV, T, SPARE, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
     }
     return launch_lr_t2<DPL, IT, NV, T, SPARE, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
 }
 
 template <typename IT, int NV>
 static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, int D, float *disp_l, float *disp_r, u32 fu,
-                       int sub)
+                       int sub, bool sw4)
 {
     // LDS ring: (tiles) x D x (T+2) u16 must fit 160 KiB
-    if (D == 64) return launch_lr_t<4, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
-    if (D == 128) return launch_lr_t<8, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
-    if (D == 192) return launch_lr_t<12, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
-    return launch_lr_t<16, IT, NV, 32, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub); // D = 256: 153 KiB
+    if (D == 64) return launch_lr_t<4, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub, sw4);
+    if (D == 128) return launch_lr_t<8, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub, sw4);
+    if (D == 192) return launch_lr_t<12, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub, sw4);
+    return launch_lr_t<16, IT, NV, 32, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub, sw4); // D = 256: 153 KiB
 }
 
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
@@ -1410,15 +1419,15 @@ int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const vo
 {
     // 8 single-path volumes: two groups of four are added as bytes; 4 volumes (band-marching variant): they hold
     // sums of up to three paths, so all of them together must fit a byte
-    g_sum_sw4 = elem_bytes == 1 && max_path_value > 0 && (nvol == 8 ? 4 * max_path_value <= 255 : 8 * max_path_value <= 255);
+    const bool sw4 = elem_bytes == 1 && max_path_value > 0 && (nvol == 8 ? 4 * max_path_value <= 255 : 8 * max_path_value <= 255);
     if ((D != 64 && D != 128 && D != 192 && D != 256) || (nvol != 8 && nvol != 4)) return 1; // caller falls back
     VolPtrs vp;
     for (int i = 0; i < 8; i++) vp.v[i] = i < nvol ? vols[i] : nullptr;
     if (elem_bytes == 1) {
-        if (nvol == 8) return launch_lr_d<u8, 8>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub);
-        return launch_lr_d<u8, 4>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub);
+        if (nvol == 8) return launch_lr_d<u8, 8>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub, sw4);
+        return launch_lr_d<u8, 4>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub, sw4);
     }
-    if (nvol == 8) return launch_lr_d<u16, 8>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub);
+    if (nvol == 8) return launch_lr_d<u16, 8>(ctx, vp, B, Hp, Wp, D, disp_l, disp_r, fu, sub, false);
     return 1;
 }
 
