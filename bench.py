@@ -5,23 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Metric (BASELINE.json): Mdisparities/s = frames * H * W * D / wall-seconds / 1e6 for
-VPP (rnd, reference defaults) + rSGM at 540x960, D=192, 3 % hints; inputs are resident in HBM
-when the timed region starts.  A "step" is one pass of the whole hot path (vppx_vpp_rsgm_dev)
-over one batch of B synthetic frames per GPU.  Frames shard over ranks with no data-path
-collective ("weak" scaling: B frames per GPU); the only exchange is the final gather of the
-disparity maps to rank 0, which is inside the timed region for N > 1.
+occlusion heuristic + VPP (rnd, reference defaults) + rSGM at 540x960, D=192, 3 % hints; inputs are
+resident in HBM when the timed region starts.  A "step" is one pass of the whole hot path
+(filter.occlusion_heuristic -> vpp -> compute_rsgm, i.e. test.py:154-225 with --maskocc) over one batch of B
+synthetic frames per GPU.  Frames shard over ranks with no data-path collective ("weak" scaling: B frames
+per GPU); the only exchange is the final gather of the disparity maps to rank 0, inside the timed region.
+
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts N rank processes itself, before
+this process has made any GPU call, and exits with the first non-zero rank status.
 
 One JSON line is printed by rank 0.  Extra objects:
-  roofline     -- dominant kernel (8-path aggregation): algorithmic bytes per launch
-                  (10 B/cell of SURVEY 8d's 16 B/cell) / average
-                  launch duration measured with hipEvents on the launch stream, vs 8 TB/s.
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference's own
-                  rSGM natives are not in its tree) timed on this box's host cores on a
-                  bounded sample, rank 0, N=1 only.
+  roofline     -- dominant kernel (8-path aggregation): algorithmic bytes per launch (10 B/cell of SURVEY
+                  8d's 16 B/cell) / average launch duration measured with hipEvents
+                  on the launch stream, vs 8 TB/s; next to it the PMC view of the same kernel (real HBM
+                  bytes, VALU issue time) from the committed profile of THIS kernel source (else null).
+  b1           -- the literal cfg-2 "single pair": latency of one frame per call.
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference's own rSGM natives
+                  are not in its tree) timed on this box's host cores on a bounded sample, rank 0, N=1.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,18 +41,21 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 AGG_BYTES_PER_CELL = 10.0        # aggregation share of the 16 B/cell algorithmic bytes
 PATH_BYTES_PER_CELL = 16.0       # whole path, + 50 B/pixel
 PATH_BYTES_PER_PIXEL = 50.0
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames timed for the 1-thread CPU baseline (0 = skip both CPU legs)")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--cpu-parallel", action="store_true", help="also time the CPU port on up to 32 host cores")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--no-cpu-parallel", action="store_true", help="skip the all-cores CPU leg")
+    ap.add_argument("--no-occ", action="store_true", help="headline run without the occlusion mask (g_occ = None)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend for N > 1 (default nccl = RCCL; gloo when the "
+                                                    "ranks have to share a GPU: dry runs)")
     ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
                     help="other BASELINE configs, e.g. --shape 375 1242 192 0.05 (KITTI) or 1536 2048 256 0.01")
     ap.add_argument("--graph", action="store_true",
@@ -53,23 +63,123 @@ def parse():
     ap.add_argument("--uniform-random", action="store_true",
                     help="uniform-random u8 images and hint values (the variant SURVEY section 6 timed on the CPU) "
                          "instead of the textured scenes; GPU timing only")
-    return ap.parse_args()
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="rank processes only form the process group (gloo, CPU) and report the frame plan: launcher self-test")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------
+# N-rank launch and the frame plan (no GPU call in here)
+# ------------------------------------------------------------------------------------------------
+def frame_plan(batch, rank, world, base_seed=1):
+    """Frames of one step: `batch` per rank (weak scaling), rank r owns the contiguous global frames [lo, hi);
+    frame f draws from srand(base_seed + f) wherever it runs."""
+    from vppstereo_amd import dist as vdist
+    n_total = batch * world
+    lo, hi = vdist.shard_range(n_total, rank, world)
+    return dict(n_total=n_total, lo=lo, hi=hi, seed0=vdist.frame_seed(base_seed, lo))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """Start n fresh rank processes of this script (one per GPU) and wait for them.  Nothing in this process has
+    touched the GPU: `torch.cuda.device_count()` does not initialise it on this image."""
+    extra = []
+    if "--backend" not in argv and "--spawn-check" not in argv:
+        try:
+            import torch
+            if torch.cuda.device_count() < n:
+                extra = ["--backend", "gloo"]  # ranks must share a device: RCCL refuses duplicate GPUs
+        except Exception:
+            pass
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv) + extra, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def spawn_check(args):
+    """Launcher self-test (CPU, gloo): every rank reports its frame plan, rank 0 prints what it saw."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    plan = frame_plan(args.batch, rank, world)
+    seen = 1
+    rows = [[plan["lo"], plan["hi"], plan["seed0"]]]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = dist.get_world_size()
+        t = torch.tensor(rows[0], dtype=torch.int64)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        rows = [o.tolist() for o in out]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "ranks_seen": seen, "frames_per_step": plan["n_total"], "plan": rows}), flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline legs
+# ------------------------------------------------------------------------------------------------
 def _cpu_one_frame(f):
-    """VPP (rnd) + rSGM of synthetic frame f with the CPU oracle; returns (seconds, disparity)."""
+    """occlusion heuristic + VPP (rnd) + rSGM of synthetic frame f with the CPU oracle; returns (seconds, disparity)."""
     import oracle
     import synth
     fr = synth.make_frame(H, W, D, P_HINTS, seed=1234, frame=f)
     t0 = time.perf_counter()
     oracle.init_rand(1 + f)
-    lv, rv = oracle.vpp(fr["left"], fr["right"], fr["hints"])
+    occ = None if _CPU_NO_OCC else oracle.occlusion_heuristic(fr["hints"])[1]
+    lv, rv = oracle.vpp(fr["left"], fr["right"], fr["hints"], g_occ=occ)
     disp = oracle.compute_rsgm(fr["left"], lv, rv, dmax=D, subpixel=True)
     return time.perf_counter() - t0, disp
 
 
+_CPU_NO_OCC = False
+
+
 def _cpu_worker(f):
     return _cpu_one_frame(f)[0]
+
+
+def _oracle_flags():
+    try:
+        with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+            for line in f:
+                if line.startswith("CFLAGS"):
+                    return line.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    return "?"
 
 
 def cpu_baseline(n_frames, gpu_out=None):
@@ -83,13 +193,14 @@ def cpu_baseline(n_frames, gpu_out=None):
             e = float(abs(disp - gpu_out[f]).mean())
             epe = e if epe is None else max(epe, e)
     base = dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port",
-                sample=f"{n_frames} full {H}x{W}x{D} frames (VPP rnd + rSGM), oracle/liboracle.so gcc -O2, 1 thread, "
-                       f"{t_tot / n_frames:.2f} s/frame, host has {os.cpu_count()} cpus")
+                sample=f"{n_frames} full {H}x{W}x{D} frames (occlusion heuristic + VPP rnd + rSGM), oracle/liboracle.so "
+                       f"gcc {_oracle_flags().split(' -fPIC')[0]}, 1 thread, {t_tot / n_frames:.2f} s/frame, "
+                       f"host has {os.cpu_count()} cpus")
     return base, epe
 
 
-def cpu_baseline_parallel(max_procs=32):
-    """Same port, frames in parallel over host cores (one process per frame)."""
+def cpu_baseline_parallel(max_procs=16):
+    """Same port, one frame per process over the host cores (bounded: one frame each, <= 16 processes)."""
     import multiprocessing as mp
     n = max(1, min(max_procs, (os.cpu_count() or 1)))
     ctx = mp.get_context("fork")
@@ -102,14 +213,48 @@ def cpu_baseline_parallel(max_procs=32):
                        f"mean {sum(per) / n:.2f} s/frame/core")
 
 
-def main():
-    global H, W, D, P_HINTS
-    args = parse()
+def kernel_source_sha():
+    """Identity of the HIP sources the PMC profile belongs to (profiles go stale when a kernel changes)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vppstereo_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_view(agg_frames, kernel_ms):
+    """PMC numbers of the aggregation kernel from the committed profile, or None when the profile was taken from
+    other kernel sources / another batch size."""
+    try:
+        with open(PMC_PROFILE) as f:
+            pmc = json.load(f)
+    except Exception:
+        return None
+    if pmc.get("kernel_source_sha") != kernel_source_sha() or pmc.get("batch") != agg_frames or \
+            (pmc.get("H"), pmc.get("W"), pmc.get("D")) != (H, W, D):
+        return None
+    k = pmc.get("kernels", {}).get("sgm_paths_kernel")
+    if not k:
+        return None
+    out = dict(k)
+    out["profile"] = os.path.relpath(PMC_PROFILE, ROOT)
+    out["profile_commit"] = pmc.get("commit")
+    if "hbm_GB_per_launch" in k and kernel_ms > 0:
+        out["hbm_frac_of_peak"] = round(k["hbm_GB_per_launch"] / (kernel_ms * 1e-3) / HBM_PEAK_GBS, 4)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def run_rank(args):
+    global H, W, D, P_HINTS, _CPU_NO_OCC
     if os.environ.get("BENCH_DEBUG"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_DEBUG"]), exit=True)
     if args.shape:
         H, W, D, P_HINTS = int(args.shape[0]), int(args.shape[1]), int(args.shape[2]), float(args.shape[3])
+    _CPU_NO_OCC = args.no_occ
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -120,17 +265,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher decides; reporting n_gpus={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
     dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)  # dry runs: several ranks on one GPU
     torch.cuda.set_device(dev_index)
+    backend = args.backend or ("nccl" if world <= ndev else "gloo")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
     eng = Engine(dev_index)
     if args.graph:
@@ -138,8 +286,8 @@ def main():
         eng.set_graph_mode(True)
 
     B = args.batch
-    n_total = B * world
-    lo, hi = vdist.shard_range(n_total, rank, world)
+    plan = frame_plan(B, rank, world)
+    n_total, lo, seed0 = plan["n_total"], plan["lo"], plan["seed0"]
     # synthetic frames: a few distinct scenes tiled over the batch (generation is host-side numpy)
     n_unique = min(B, 4)
     if args.uniform_random:
@@ -153,31 +301,34 @@ def main():
     left = torch.from_numpy(np.ascontiguousarray(base["left"][idx])).to(dev)
     right = torch.from_numpy(np.ascontiguousarray(base["right"][idx])).to(dev)
     hints = torch.from_numpy(np.ascontiguousarray(base["hints"][idx])).to(dev)
-    outs = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
-    out = outs[0]
-    seed0 = vdist.frame_seed(1, lo)
-    pending = [None, None]  # gathers in flight, one per output buffer
+    # --graph replays one captured call: a single output buffer keeps its arguments identical from step to step
+    n_out = 1 if args.graph else 2
+    outs = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(n_out)]
+    occ_buf = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    pending = [None] * n_out  # gathers in flight, one per output buffer
     nstep = [0]
 
-    def local_step(buf=None):
-        buf = out if buf is None else buf
-        eng.vpp_rsgm(left, right, hints, out=buf, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1))
+    def local_step(buf, use_occ=True, lft=left, rgt=right, hnt=hints, occb=occ_buf):
+        occ = eng.occlusion_heuristic(hnt, out=occb) if use_occ else None   # test.py:154 (--maskocc)
+        eng.vpp_rsgm(lft, rgt, hnt, g_occ=occ, out=buf, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1))
         return buf
+
+    use_occ = not args.no_occ
 
     def step():
         # the gather of step k (to rank 0, asynchronous) overlaps the kernels of step k+1, which write the
         # other output buffer; a buffer is reused only after its previous gather has completed
-        k = nstep[0] % 2
+        k = nstep[0] % n_out
         nstep[0] += 1
         if pending[k] is not None:
             pending[k].wait()
             pending[k] = None
-        local_step(outs[k])
+        local_step(outs[k], use_occ)
         if world > 1 and not args.no_gather:
             pending[k] = vdist.gather_disparities_async(outs[k], n_total, dst=0)  # every rank calls step() equally often
 
     def drain():
-        for k in range(2):
+        for k in range(n_out):
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
@@ -194,33 +345,43 @@ def main():
         except Exception as e:  # noqa: BLE001
             ok = 0
             print(f"[bench] rank {rank}: result gather failed ({type(e).__name__}: {e}); running without it", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             args.no_gather = True
             gather_note = "result gather to rank 0 unavailable: shards stay on their ranks"
 
+    def timed(n_steps, fn):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            fn()
+        drain()  # the last gathers complete inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     for _ in range(args.warmup):
         step()
     drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     eng.agg_kernel_ms(0)  # reset: the hipEvent pairs around the aggregation launches of the timed steps only
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()  # the last gathers complete inside the timed region
-    torch.cuda.synchronize()
+    dt_local = timed(args.steps, step)
+    dt = dt_local
+    rank_ms = [dt_local / args.steps * 1e3]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([dt_local], dtype=torch.float64, device=cdev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
+        dt = max(float(x.item()) for x in allt)
+    if args.graph:
+        assert eng.graph_replays() > 0, "--graph was given but no call was served by a graph replay"
 
     ms_per_step = dt / args.steps * 1e3
     value = n_total * H * W * D * args.steps / dt / 1e6
@@ -231,51 +392,73 @@ def main():
         # average over the launches made INSIDE the timed region (event pairs on the launch stream, ring of 64)
         agg_ms, agg_n = eng.agg_kernel_ms(args.steps)
         agg_ms_b2b = eng.time_aggregate(iters=max(3, min(10, args.steps)))  # same kernel re-launched back to back
+        if agg_n == 0 or agg_ms <= 0:   # graph replays carry no event pairs
+            agg_ms = agg_ms_b2b
         agg_frames = eng.time_aggregate_frames()  # frames per launch (the batch is split over sub-streams)
         Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
         cells_launch = agg_frames * Hp * Wp * D
         achieved = cells_launch * AGG_BYTES_PER_CELL / (agg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH correction
-        # applied); only meaningful for the batch size they were collected at
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("batch") == agg_frames and (H, W, D) == (540, 960, 192):
-                for name, d in pmc["kernels"].items():
-                    if name.startswith(("void sgm_paths_kernel", "sgm_paths_kernel")) and "hbm_GB_per_launch_corrected" in d:
-                        traffic = d["hbm_GB_per_launch_corrected"]
-        except Exception:
-            traffic = None
+        pmc = pmc_view(agg_frames, agg_ms)
+        # the same step without the occlusion mask (the reference's default, test.py --maskocc off): rank-local, no collectives
+        other = None
+        if world == 1:
+            n2 = max(2, min(5, args.steps))
+            local_step(outs[0], not use_occ)
+            dt2 = timed(n2, lambda: local_step(outs[0], not use_occ))
+            other = round(dt2 / n2 * 1e3, 3)
+        # ---- the literal cfg 2: one pair per call ------------------------------------------------
+        l1, r1, h1, o1 = left[:1].contiguous(), right[:1].contiguous(), hints[:1].contiguous(), occ_buf[:1]
+        out1 = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            local_step(out1, use_occ, l1, r1, h1, o1)
+        torch.cuda.synchronize()
+        n1 = 20
+        t0 = time.perf_counter()
+        for _ in range(n1):
+            local_step(out1, use_occ, l1, r1, h1, o1)
+        torch.cuda.synchronize()
+        b1_ms = (time.perf_counter() - t0) / n1 * 1e3
         eng.enable_stage_timing(True)
         for _ in range(2):  # first pass sizes the un-split workspace; report the second
-            local_step()    # rank-0-only section: no collectives here
+            local_step(outs[0], use_occ)    # rank-0-only section: no collectives here
             torch.cuda.synchronize()
         stages = eng.stage_ms()
         eng.enable_stage_timing(False)
         pipeline_gbs = value * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / D) / 1e9
+        occ_txt = "occlusion heuristic + " if use_occ else ""
         result = {
             "metric": f"Mdisparities/s (HxWxD / s) VPP+rSGM at {H}x{W}xD={D}",
             "value": round(value, 1), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u16",
             "data": "synthetic (uniform random u8)" if args.uniform_random else "synthetic",
-            "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
+            "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, {occ_txt}VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
                                    f"{B} frames/GPU/step resident in HBM", "frames_per_step": n_total,
-                       "H": H, "W": W, "D": D, "hint_density": P_HINTS},
-            "roofline": {"bound": "hbm", "kernel": "sgm_paths_kernel (8-path aggregation)",
+                       "H": H, "W": W, "D": D, "hint_density": P_HINTS, "g_occ": "occlusion_heuristic" if use_occ else None},
+            "ranks": {"launched": args.gpus, "seen": dist.get_world_size() if world > 1 else 1,
+                      "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
+                      "ms_per_step_per_rank": [round(x, 3) for x in rank_ms]},
+            "roofline": {"bound": "valu", "kernel": "sgm_paths_kernel (8-path aggregation)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, committed profile)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None,
+                         "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; null unless the committed profile "
+                                         "was taken from these kernel sources at this batch size)",
+                         "pmc": pmc,
                          "algorithmic_GB_per_launch": round(cells_launch * AGG_BYTES_PER_CELL / 1e9, 3),
                          "kernel_ms": round(agg_ms, 4), "kernel_launches_timed": agg_n,
                          "kernel_ms_back_to_back": round(agg_ms_b2b, 4), "bytes_per_cell": AGG_BYTES_PER_CELL,
-                         "frames_per_launch": agg_frames, "cells_per_launch": cells_launch},
+                         "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,
+                         "note": "HBM-roofline convention of SURVEY 8d; the kernel itself is issue-bound (VALU + store issue, "
+                                 "DESIGN section 6), hence bound = valu"},
             "pipeline_roofline": {"bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,
                                   "achieved_GBps": round(pipeline_gbs, 1),
                                   "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4)},
+            ("ms_per_step_without_g_occ" if use_occ else "ms_per_step_with_g_occ"): other,
+            "b1": {"ms_per_frame": round(b1_ms, 4), "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),
+                   "what": "one frame per call (B=1), host-paced loop of 20 calls, same stages as the step"},
             "stage_ms": {k: round(v, 3) for k, v in stages.items()},
+            "kernel_source_sha": kernel_source_sha(),
             "device": eng.ctx.device_name,
         }
         if args.graph:
@@ -283,11 +466,11 @@ def main():
         if world > 1:
             result["config"]["result_gather"] = gather_note or ("off" if args.no_gather else "async gather to rank 0, overlapped")
         if world == 1 and args.cpu_frames > 0:
-            gpu_out = out[: min(args.cpu_frames, n_unique)].cpu().numpy()
+            gpu_out = local_step(outs[0], use_occ)[: min(args.cpu_frames, n_unique)].cpu().numpy()
             result["cpu_baseline"], epe = cpu_baseline(min(args.cpu_frames, n_unique), gpu_out)
             result["epe_vs_cpu_oracle"] = epe      # mean |disp_gpu - disp_cpu|, worst frame (0.0 = bit-equal)
             result["speedup_vs_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
-            if args.cpu_parallel:
+            if not args.no_cpu_parallel:
                 result["cpu_baseline_all_cores"] = cpu_baseline_parallel()
         else:
             result["cpu_baseline"] = None
@@ -296,6 +479,16 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, argv))
+    if args.spawn_check:
+        sys.exit(spawn_check(args))
+    return run_rank(args)
 
 
 if __name__ == "__main__":

@@ -169,6 +169,10 @@ int vppx_cost_census5x5_xyd(vppx_ctx *ctx, const uint32_t *cl, const uint32_t *c
                             int dmax, int n_threads_ignored);
 int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t *dsi, uint16_t *dsi_agg, int w, int h,
                    int dmax, int p1, int p2min, float alpha, int gamma);
+/* The same with the image as the reference's glue passes it (rsgm.py:258,270: the padded H x W x 3 colour array):
+ * channels = 3 converts to gray on the device first, so that this route and vppx_rsgm_* use the same P2 image. */
+int vppx_aggregate_img(vppx_ctx *ctx, const uint8_t *img, int channels, const uint16_t *dsi, uint16_t *dsi_agg, int w,
+                       int h, int dmax, int p1, int p2min, float alpha, int gamma);
 int vppx_match_wta(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax, float uniqueness);
 int vppx_match_wta_right(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w, int h, int dmax,
                          float uniqueness);

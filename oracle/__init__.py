@@ -21,6 +21,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# ORACLE_LIB: use another build of the same sources, e.g. the ASan/UBSan one (`make -C oracle asan`; CPU only)
+_LIB_OVERRIDE = os.environ.get("ORACLE_LIB")
 
 
 def build(force=False):
@@ -39,8 +41,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        if _LIB_OVERRIDE:
+            _lib = C.CDLL(_LIB_OVERRIDE)
+        else:
+            build()
+            _lib = C.CDLL(_LIB_PATH)
         _lib.vppo_rand.restype = C.c_int
         _lib.rsgmo_compute_rsgm.restype = C.c_int
     return _lib
@@ -188,6 +193,15 @@ def aggregate_SSE(img, dsi, dsi_agg, w, h, dmax, p1, p2min, alpha, gamma, path_m
     assert img.dtype == np.uint8 and img.shape == (h, w)
     lib().rsgmo_aggregate_paths(_u8(img), _p(dsi, C.c_uint16), _p(dsi_agg, C.c_uint16), int(w), int(h), int(dmax),
                                 int(p1), int(p2min), C.c_float(alpha), int(gamma), int(path_mask))
+
+
+def _guided_dsi(dsi, hints, validhints):
+    """rsgm.py:116-127: returns the re-weighted copy (uint16)."""
+    out = np.ascontiguousarray(dsi, np.uint16).copy()
+    h, w, dmax = out.shape
+    lib().rsgmo_guided_dsi(_p(out, C.c_uint16), _f32(np.ascontiguousarray(hints, np.float32)),
+                           _f32(np.ascontiguousarray(validhints, np.float32)), int(w), int(h), int(dmax))
+    return out
 
 
 def matchWTA_SSE(dsi, disp, w, h, dmax, uniqueness):

@@ -172,6 +172,21 @@ def main():
     out["gm_out"] = np.asarray([m['bad 1.0'], m['bad 2.0'], m['bad 3.0'], m['bad 4.0'], m['avgerr'], m['rms']],
                                np.float64)
 
+    # ---------------------------------------------------------------- _guided_dsi (rsgm.py:116-127)
+    # plain NumPy follows numba here: float32 hint - int64 arange -> float64, everything after it float64,
+    # astype(uint16) truncates.  Own generator so that the arrays above keep their values.
+    rg = np.random.default_rng(777)
+    for i, (h, w, dmax, p) in enumerate([(6, 16, 32, 0.3), (5, 16, 64, 1.0)]):
+        dsi = rg.integers(0, 25, (h, w, dmax)).astype(np.uint16)
+        valid = (rg.random((h, w)) < p).astype(np.float32)
+        hints = (rg.uniform(0, dmax - 1, (h, w)) * valid).astype(np.float32)
+        if i == 1:
+            hints = np.round(hints * 4) / 4          # quarter-pixel hints: exact zeros of (h - d) included
+            hints = hints.astype(np.float32)
+        res = ref_rsgm._guided_dsi(dsi.copy(), hints, valid)
+        assert res.dtype == np.uint16
+        out[f"gdsi{i}_dsi"], out[f"gdsi{i}_hints"], out[f"gdsi{i}_valid"], out[f"gdsi{i}_out"] = dsi, hints, valid, res
+
     np.savez_compressed(os.path.join(HERE, "glue_cases.npz"), **out)
     print("wrote", len(out), "arrays")
 

@@ -71,3 +71,10 @@ def test_guided_metrics(G):  # losses.py:13-24
     m = oracle.guided_metrics(G["gm_disp"], G["gm_gt"], G["gm_valid"])
     got = np.asarray([m['bad 1.0'], m['bad 2.0'], m['bad 3.0'], m['bad 4.0'], m['avgerr'], m['rms']])
     assert np.allclose(got, G["gm_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_guided_dsi(G):  # rsgm.py:116-127
+    for i in range(2):
+        got = oracle._guided_dsi(G[f"gdsi{i}_dsi"], G[f"gdsi{i}_hints"], G[f"gdsi{i}_valid"])
+        assert got.dtype == np.uint16 and np.array_equal(got, G[f"gdsi{i}_out"]), i
+        assert not np.array_equal(got, G[f"gdsi{i}_dsi"])

@@ -45,6 +45,7 @@ struct VppK {
     double inv_gamma;
     u8 *l;
     u8 *r;
+    const u8 *r_src; // un-patterned right image for the L side's R sub-chains (= r unless the caller kept the original)
     const float *g;
     const u8 *occ;       // may be null
     const float *filled; // may be null
@@ -537,6 +538,36 @@ __device__ __forceinline__ bool rng_hit(u32 rg, int q, int W)
 __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim_y, int lim_i, int lim_xw)
 {
     const int W = k.W, H = k.H;
+    // the pixel's hint list (rlist_kernel has run before every caller) names exactly the hints that can touch it:
+    // replay those up to the limit key instead of scanning the hint rows (a few entries instead of ~3 rows of hints)
+    if (k.rcnt != nullptr && lim_y < H) {
+        const size_t pidx = ((size_t)f * H + yp) * W + q;
+        const int n = k.rcnt[pidx];
+        if (n <= RLCAP) {
+            if (n == 0) return;
+            static_assert(RLCAP == 8, "list record = 2 x uint4");
+            u32 ids[RLCAP];
+            const uint4 a = ((const uint4 *)k.rlist)[pidx * 2], b = ((const uint4 *)k.rlist)[pidx * 2 + 1];
+            ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w;
+            ids[4] = b.x; ids[5] = b.y; ids[6] = b.z; ids[7] = b.w;
+#pragma unroll
+            for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? ids[i] : 0xFFFFFFFFu;
+#define CS(a, b) { const u32 lo_ = min(ids[a], ids[b]), hi_ = max(ids[a], ids[b]); ids[a] = lo_; ids[b] = hi_; }
+            CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
+            CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
+#undef CS
+            const u32 lim = ((u32)lim_y << 16) | (u32)min(lim_i, 0xFFFF);
+            const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+#pragma unroll
+            for (int i = 0; i < RLCAP; i++) {
+                if (i < n && ids[i] <= lim) {
+                    const int yy = (int)(ids[i] >> 16), hi = (int)(ids[i] & 0xFFFFu);
+                    r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], ids[i] == lim ? lim_xw : 0x7FFFFFFF);
+                }
+            }
+            return;
+        }
+    }
     const int ylo = max(0, yp - k.n), yhi = min(min(H - 1, yp + k.n), lim_y);
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
     for (int yy = ylo; yy <= yhi; yy++) {
@@ -738,8 +769,8 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
                 int q1 = xd1 + xw;
                 q1 = q1 < 0 ? q1 + W : q1;                           // unguarded read, pyx:119
                 u8 R0[4], R1[4];
-                const u8 *r0p = k.r + (((size_t)f * H + yp) * W + q0) * k.C;
-                const u8 *r1p = k.r + (((size_t)f * H + yp) * W + q1) * k.C;
+                const u8 *r0p = k.r_src + (((size_t)f * H + yp) * W + q0) * k.C;
+                const u8 *r1p = k.r_src + (((size_t)f * H + yp) * W + q1) * k.C;
                 for (int j = 0; j < 4; j++) { R0[j] = j < k.C ? r0p[j] : 0; R1[j] = j < k.C ? r1p[j] : 0; }
                 r_chain(k, f, yp, q0, R0, yy, (int)dn.x, xw);
                 if (q1 == q0) {
@@ -752,7 +783,7 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
                 int qd = xd + xw;
                 qd = qd < 0 ? qd + W : qd;
                 u8 Rd[4];
-                const u8 *rdp = k.r + (((size_t)f * H + yp) * W + qd) * k.C;
+                const u8 *rdp = k.r_src + (((size_t)f * H + yp) * W + qd) * k.C;
                 for (int j = 0; j < 4; j++) Rd[j] = j < k.C ? rdp[j] : 0;
                 r_chain(k, f, yp, qd, Rd, yy, (int)dn.x, xw);
                 for (int j = 0; j < k.C; j++) L[j] = blend_l_occ_ni(Rd[j], k.c, L[j]);
@@ -1244,7 +1275,7 @@ static Poly31 qoff_for(u64 rand_offset)
 }
 
 int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u8 *r, const float *gmap,
-               const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev)
+               const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev, const u8 *r_orig)
 {
     if (g.C < 1 || g.C > 4) { vppx_set_error("channels must be 1..4 (got %d)", g.C); return VPPX_E_INVALID_ARG; }
     if (p.wsize < 1 || p.wsize > 31) { vppx_set_error("wsize must be in 1..31 (got %d)", p.wsize); return VPPX_E_INVALID_ARG; }
@@ -1263,7 +1294,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     k.use_bil = (p.use_bilateral_patch != 0) && filled_g != nullptr;
     k.c = p.c; k.c_occ = p.c_occ; k.dmin = p.dmin; k.dmax = p.dmax;
     k.inv_gamma = 1.0 / p.distance_gamma;
-    k.l = l; k.r = r; k.g = gmap; k.occ = occ; k.filled = filled_g;
+    k.l = l; k.r = r; k.r_src = r_orig ? r_orig : r; k.g = gmap; k.occ = occ; k.filled = filled_g;
     const size_t npx = (size_t)g.B * g.H * g.W;
     int rc;
     if ((rc = ws_get(ctx, WS_HINT_REC, npx, &k.rec))) return rc;
@@ -1326,9 +1357,13 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     if ((rc = ws_get(ctx, WS_RLIST, npx * RLCAP, &k.rlist))) return rc;
     // The L side reads R only for occluded hints (pyx:114-122).  Without an occlusion mask the two sides are
     // independent: the (latency-bound) L kernels then run on the side stream next to the R list build + replay.
-    const bool split = (occ == nullptr) && ctx->stream2 != nullptr;
+    // With a mask the L side replays R sub-chains from the pixels' hint lists and the ORIGINAL right image: when the
+    // caller kept that image (fused path: the patterned pair is a copy) the fork happens after the list build.
+    const bool split_early = (occ == nullptr) && ctx->stream2 != nullptr;
+    const bool split_late = !split_early && r_orig != nullptr && r_orig != r && ctx->stream2 != nullptr;
+    const bool split = split_early || split_late;
     hipStream_t ls = ctx->stream;
-    if (split) {
+    if (split_early) {
         VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         ls = ctx->stream2;
@@ -1336,6 +1371,11 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
     rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
+    if (split_late) {
+        VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        ls = ctx->stream2;
+    }
     switch (k.n) { // sparse frames (each frame picks one of the two mappings on the device)
     case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
     case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
@@ -1458,31 +1498,40 @@ __global__ void __launch_bounds__(256) occ_conf_kernel(const float *__restrict__
                                                        int ry, double l, double g, double th)
 {
     // weighted_conf (filter.py:115-164), gather form: pixel n is rejected if it is invalid, or if
-    // some valid centre c with n in c's window is nearer (larger) by more than the weighted distance
+    // some valid centre c with n in c's window is nearer (larger) by more than the weighted distance.
+    // Valid pixels are sparse (the warped hints, a few per cent): instead of one lane walking the whole
+    // (2rx+1) x (2ry+2) window of its pixel while 60 lanes idle, the wave takes its valid pixels one after the
+    // other and tests all window positions of that pixel at once, one per lane.
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, f = blockIdx.z;
-    if (x >= W) return;
+    const int lane = threadIdx.x & 63;
     const float *om = omap + (size_t)f * H * W;
-    const float dn = om[(size_t)y * W + x];
-    u8 cf = 0;
-    if (!(dn > 0)) {
-        cf = 1;
-    } else {
-        // centre (yc,xc) = (y - yw, x - xw) with xw in [-rx,rx], yw in [-ry-1, ry]  (asymmetric, :149)
-        for (int xw = -rx; xw <= rx && !cf; xw++)
-            for (int yw = -ry - 1; yw <= ry; yw++) {
-                const int yc = y - yw, xc = x - xw;
-                if (yc < 0 || yc > H - 1 || xc < 0 || xc > W - 1) continue;
-                const float dc = om[(size_t)yc * W + xc];
-                if (dc > 0 && dn < dc) {
-                    const double t = __dsub_rn((double)__fsub_rn(dc, dn),
-                                               __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xw)),
-                                                                      __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw)))));
-                    if (t > th) { cf = 1; break; }
-                }
+    const float dn = x < W ? om[(size_t)y * W + x] : 0.0f;
+    const bool valid = dn > 0;
+    u8 cf = valid ? 0 : 1;
+    const int nyw = 2 * ry + 2, nwin = (2 * rx + 1) * nyw; // centre = (y - yw, x - xw), xw in [-rx,rx], yw in [-ry-1,ry] (:149)
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int xs = __builtin_amdgcn_readlane(x, src);
+        const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn), src));
+        bool hit = false;
+        for (int kpos = lane; kpos < nwin; kpos += 64) {
+            const int xw = kpos / nyw - rx, yw = kpos % nyw - ry - 1;
+            const int yc = y - yw, xc = xs - xw;
+            if (yc < 0 || yc > H - 1 || xc < 0 || xc > W - 1) continue;
+            const float dc = om[(size_t)yc * W + xc];
+            if (dc > 0 && ds < dc) {
+                const double t = __dsub_rn((double)__fsub_rn(dc, ds),
+                                           __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xw)),
+                                                                  __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw)))));
+                hit = hit || (t > th);
             }
+        }
+        if (__builtin_amdgcn_ballot_w64(hit) != 0 && lane == src) cf = 1;
     }
-    conf[((size_t)f * H + y) * W + x] = cf;
+    if (x < W) conf[((size_t)f * H + y) * W + x] = cf;
 }
 __global__ void __launch_bounds__(256) occ_unwarp_kernel(const float *__restrict__ omap, const u8 *__restrict__ conf,
                                                          int *__restrict__ tmp, int H, int W, double th_filter)

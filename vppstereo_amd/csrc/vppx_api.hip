@@ -761,7 +761,7 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmPa
         if ((rc = vpp_launch_bilateral_fill(ctx, *vp, vg, left, g, fg))) return rc;
         filled_g = fg;
     }
-    if ((rc = vpp_launch(ctx, *vp, vg, l_vpp, r_vpp, g, g_occ, filled_g, nullptr, nullptr))) return rc;
+    if ((rc = vpp_launch(ctx, *vp, vg, l_vpp, r_vpp, g, g_occ, filled_g, nullptr, nullptr, right))) return rc;
     RsgmGeom rg;
     make_geom(B, H, W, C, rp->dmax, rg);
     return rsgm_core(ctx, *rp, rg, left, l_vpp, r_vpp, disp_out);
@@ -1015,9 +1015,19 @@ extern "C" int vppx_cost_census5x5_xyd(vppx_ctx *ctx, const uint32_t *cl, const 
 extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t *dsi, uint16_t *dsi_agg, int w, int h,
                               int dmax, int p1, int p2min, float alpha, int gamma)
 {
+    return vppx_aggregate_img(ctx, img, 1, dsi, dsi_agg, w, h, dmax, p1, p2min, alpha, gamma);
+}
+
+// rsgm.py:270 hands aggregate_SSE the padded H x W x 3 COLOUR image although the native reads one byte per pixel.
+// What upstream does with it is unknown (parity unpinned); this build defines the P2 image of every route as
+// gray(left), so a 3-channel image is converted on the device exactly like the fused compute_rsgm does.
+extern "C" int vppx_aggregate_img(vppx_ctx *ctx, const uint8_t *img, int channels, const uint16_t *dsi, uint16_t *dsi_agg,
+                                  int w, int h, int dmax, int p1, int p2min, float alpha, int gamma)
+{
     int rc;
     VPPX_ENTER(ctx);
     if (!img || !dsi || !dsi_agg || w <= 0 || h <= 0) { vppx_set_error("vppx_aggregate: bad arguments"); return VPPX_E_INVALID_ARG; }
+    if (channels != 1 && channels != 3) { vppx_set_error("vppx_aggregate: image must have 1 or 3 channels (got %d)", channels); return VPPX_E_INVALID_ARG; }
     if ((rc = check_w16(w))) return rc; // rsgm.py:51-58 order
     if ((rc = check_dmax(dmax))) return rc;
     const size_t n = (size_t)w * h, nc = n * dmax;
@@ -1029,7 +1039,16 @@ extern "C" int vppx_aggregate(vppx_ctx *ctx, const uint8_t *img, const uint16_t 
     p2_lut_host(p, lut_h, &maxp2);
     void *dimg, *ddsi, *paths;
     u16 *lut_d, *S;
-    if ((rc = upload(ctx, WS_STAGE_A, img, n, &dimg))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_A, img, n * channels, &dimg))) return rc;
+    if (channels == 3) {
+        u8 *gray;
+        if ((rc = ws_get(ctx, WS_GRAY_L, n, &gray))) return rc;
+        RsgmGeom g1;
+        g1.B = 1; g1.H = g1.Hp = h; g1.W = g1.Wp = w; g1.C = 3; g1.D = dmax;
+        g1.pad_l = g1.pad_r = g1.pad_t = g1.pad_b = 0;
+        if ((rc = rsgm_launch_pad_gray(ctx, g1, (const u8 *)dimg, gray))) return rc;
+        dimg = gray;
+    }
     if ((rc = upload(ctx, WS_DSI, dsi, nc * sizeof(u16), &ddsi))) return rc;
     if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
     VPPX_HIP(hipMemcpyAsync(lut_d, lut_h, sizeof(lut_h), hipMemcpyHostToDevice, ctx->stream));

@@ -235,7 +235,8 @@ struct VppGeom {
     int B, H, W, C;
 };
 int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u8 *r, const float *gmap,
-               const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev);
+               const u8 *occ, const float *filled_g, int64_t *n_hints_dev, const u32 *seeds_dev, const u8 *r_orig = nullptr);
+// r_orig: the un-patterned right image when r is a copy of it (lets the L and R sides run side by side with a mask)
 // _bilateral_filling (vpp_standalone.py:372-394) of the hints g guided by BGR2GRAY(left)
 int vpp_launch_bilateral_fill(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, const u8 *left, const float *gmap,
                               float *filled_out);

@@ -96,11 +96,12 @@ class Engine:
                                               _ptr(out)))
         return out
 
-    def occlusion_heuristic(self, hints, rx=9, ry=7, l=2, g=0.4375, th_conf=1, th_filter=0.1):
+    def occlusion_heuristic(self, hints, rx=9, ry=7, l=2, g=0.4375, th_conf=1, th_filter=0.1, out=None):
         torch = self.torch
         self._chk(hints, torch.float32, 3, "hints")
         B, H, W = hints.shape
-        conf = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
+        conf = torch.empty((B, H, W), dtype=torch.uint8, device=self.device) if out is None else out
+        self._chk(conf, torch.uint8, 3, "out", (B, H, W))
         self._bind_stream()
         _lib.check(self.lib.vppx_occlusion_heuristic_dev(self.ctx.handle, B, H, W, _ptr(hints), int(rx), int(ry),
                                                          float(l), float(g), float(th_conf), float(th_filter),

@@ -24,10 +24,17 @@ def costMeasureCensus5x5_xyd_SSE(cl, cr, dsi, w, h, dmax, n_threads=1):
 
 
 def aggregate_SSE(img, dsi, dsi_agg, w, h, dmax, p1, p2min, alpha, gamma):
+    """call site rsgm.py:61.  The reference's glue passes the padded H x W x 3 colour `left` here (rsgm.py:258,270)
+    although the native reads one byte per pixel; a 3-channel image is converted to gray on the device (the P2
+    image of the fused compute_rsgm), [H,W] and [H,W,1] are taken as they are, anything else is rejected."""
     lib, ctx = _h()
     assert img.dtype == np.uint8 and dsi.dtype == np.uint16 and dsi_agg.dtype == np.uint16
-    _lib.check(lib.vppx_aggregate(ctx, _lib.np_ptr(img), _lib.np_ptr(dsi), _lib.np_ptr(dsi_agg), int(w), int(h),
-                                  int(dmax), int(p1), int(p2min), float(alpha), int(gamma)))
+    img = np.ascontiguousarray(img)
+    if img.shape[:2] != (int(h), int(w)) or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] not in (1, 3)):
+        raise Exception(f"aggregate_SSE: image must be {h}x{w} with 1 or 3 channels, got shape {img.shape}")
+    ch = 3 if (img.ndim == 3 and img.shape[2] == 3) else 1
+    _lib.check(lib.vppx_aggregate_img(ctx, _lib.np_ptr(img), ch, _lib.np_ptr(dsi), _lib.np_ptr(dsi_agg), int(w), int(h),
+                                      int(dmax), int(p1), int(p2min), float(alpha), int(gamma)))
 
 
 def matchWTA_SSE(dsi, disp, w, h, dmax, uniqueness):
