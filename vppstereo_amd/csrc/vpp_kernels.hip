@@ -553,17 +553,20 @@ __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim
 #pragma unroll
             for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? ids[i] : 0xFFFFFFFFu;
 #define CS(a, b) { const u32 lo_ = min(ids[a], ids[b]), hi_ = max(ids[a], ids[b]); ids[a] = lo_; ids[b] = hi_; }
-            CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
-            CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
+            if (n == 2) {
+                CS(0, 1)
+            } else if (n > 2) { // most lists hold one or two hints
+                CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
+                CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
+            }
 #undef CS
             const u32 lim = ((u32)lim_y << 16) | (u32)min(lim_i, 0xFFFF);
             const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
-#pragma unroll
-            for (int i = 0; i < RLCAP; i++) {
-                if (i < n && ids[i] <= lim) {
-                    const int yy = (int)(ids[i] >> 16), hi = (int)(ids[i] & 0xFFFFu);
-                    r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], ids[i] == lim ? lim_xw : 0x7FFFFFFF);
-                }
+            for (int i = 0; i < n; i++) { // (a loop, not eight unrolled copies of the replay: the lists are short)
+                const u32 id = i == 0 ? ids[0] : i == 1 ? ids[1] : i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
+                if (id > lim) break;
+                const int yy = (int)(id >> 16), hi = (int)(id & 0xFFFFu);
+                r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], id == lim ? lim_xw : 0x7FFFFFFF);
             }
             return;
         }
