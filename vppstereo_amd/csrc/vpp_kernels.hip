@@ -1106,17 +1106,14 @@ __device__ void md_search(const MdK &m, const Mem &mem, int cy, int cx, int rcx,
     pb_out = pb;
 }
 
-// all hints of row y of chain (f, j), in scan order
+// one hint of row y of chain (f, j): colour search(es) + the patch blends (pyx:200-341)
 template <typename Mem>
-__device__ __forceinline__ void md_row(const MdK &m, const Mem &mem, int f, int y, u32 *hist, int &pa, int &pb)
+__device__ __forceinline__ void md_hint(const MdK &m, const Mem &mem, int f, int y, const HintRec &rec, u32 *hist, int &pa, int &pb)
 {
     const VppK &k = m.k;
     const int W = k.W, H = k.H;
     const int lane = threadIdx.x & 63;
-    const size_t rowoff = ((size_t)f * H + y) * W;
-    const int cnt = k.row_count[(size_t)f * H + y];
-    for (int i = 0; i < cnt; i++) {
-        const HintRec rec = k.rec[rowoff + i];
+    {
         HintGeo h;
         decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
         const int x = h.x;
@@ -1185,6 +1182,16 @@ __device__ __forceinline__ void md_row(const MdK &m, const Mem &mem, int f, int 
     }
 }
 
+// all hints of row y of chain (f, j), in scan order
+template <typename Mem>
+__device__ __forceinline__ void md_row(const MdK &m, const Mem &mem, int f, int y, u32 *hist, int &pa, int &pb)
+{
+    const VppK &k = m.k;
+    const size_t rowoff = ((size_t)f * k.H + y) * k.W;
+    const int cnt = k.row_count[(size_t)f * k.H + y];
+    for (int i = 0; i < cnt; i++) md_hint(m, mem, f, y, k.rec[rowoff + i], hist, pa, pb);
+}
+
 // in-place variant (any parameters)
 __global__ void __launch_bounds__(64) maxdist_kernel(MdK m)
 {
@@ -1248,6 +1255,146 @@ __global__ void __launch_bounds__(64) maxdist_lds_kernel(MdK m, int rad)
         md_row(m, mem, f, y, hist, pa, pb);
     }
     for (int r = lo; r <= hi; r++) store_row(r);
+}
+
+// ---------------------------------------------------------------------------------------
+// Row wavefront (SURVEY C-12).  Hints of one (frame, channel) chain conflict only when their footprints overlap: a
+// hint of row y reads rows y +- rad (rad = patch radius n + vertical half window) and writes rows y +- n, so rows
+// further apart than dep = n + rad never interact, and inside that band only hints whose column ranges overlap do:
+//   left image : |x1 - x2| <= 2n + n_agg_x
+//   right image: [x - ceil(g) - n - n_agg_x, x - floor(g) + n + n_agg_x] of the two hints overlap
+// (plus everything that indexes column -1 -> W-1, SURVEY C-1/C-2: such a hint waits for whole rows).
+// One workgroup of MD_NW waves owns a chain; wave w walks rows w, w + MD_NW, ...  Before a hint runs, its wave waits
+// until each of the dep rows above has completed its LAST hint that conflicts with it (the lanes test the hints of
+// such a row in parallel; a row's hints complete in index order, so one progress counter per row suffices).  Progress
+// counters, the image rows the chain works on (ring of MD_RING rows of both channel planes) and the completion order
+// live in LDS.
+// Scan direction x ascending only (direction = 1, what vpp() uses); other cases take the one-wave kernels.
+// ---------------------------------------------------------------------------------------
+#define MD_NW 16
+#define MD_RING 32
+struct MemRing {
+    u8 *sl, *sr; // [MD_RING][W]
+    int W;
+    __device__ __forceinline__ int off(int y) const { return (y & (MD_RING - 1)) * W; }
+    __device__ __forceinline__ u32 ldL(int y, int x) const { return sl[off(y) + x]; }
+    __device__ __forceinline__ u32 ldR(int y, int x) const { return sr[off(y) + x]; }
+    __device__ __forceinline__ void stL(int y, int x, u8 v) const { sl[off(y) + x] = v; }
+    __device__ __forceinline__ void stR(int y, int x, u8 v) const { sr[off(y) + x] = v; }
+    __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+};
+
+__device__ __forceinline__ int md_lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void md_lds_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ void __launch_bounds__(64 * MD_NW) maxdist_wave_kernel(MdK m, int rad)
+{
+    __shared__ u32 hist_all[MD_NW][256];
+    __shared__ int prog[2 * MD_RING]; // hints completed in row r (slot r % 32: a slot is recycled 32 rows later, long after its last reader)
+    __shared__ int done_upto;       // rows 0..done_upto are complete (completion token passes in row order)
+    __shared__ int loaded_upto;     // rows 0..loaded_upto are (or have been) resident in the ring
+    extern __shared__ __attribute__((aligned(16))) u8 md_rows[]; // [2][MD_RING][W]
+    const VppK &k = m.k;
+    const int f = blockIdx.x / k.C, j = blockIdx.x % k.C;
+    const int W = k.W, H = k.H, C = k.C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u8 *lch = k.l + (size_t)f * H * W * C + j;
+    u8 *rch = k.r + (size_t)f * H * W * C + j;
+    MemRing mem;
+    mem.sl = md_rows;
+    mem.sr = md_rows + (size_t)MD_RING * W;
+    mem.W = W;
+    u32 *hist = hist_all[wave];
+    const int dep = k.n + rad;
+    auto load_row = [&](int r) { // by one wave
+        const int o = mem.off(r);
+        for (int x = lane; x < W; x += 64) {
+            mem.sl[o + x] = lch[((size_t)r * W + x) * C];
+            mem.sr[o + x] = rch[((size_t)r * W + x) * C];
+        }
+    };
+    auto store_row = [&](int r) {
+        const int o = mem.off(r);
+        for (int x = lane; x < W; x += 64) {
+            lch[((size_t)r * W + x) * C] = mem.sl[o + x];
+            rch[((size_t)r * W + x) * C] = mem.sr[o + x];
+        }
+    };
+    // the first MD_RING rows, all waves
+    for (int r = wave; r < MD_RING && r < H; r += MD_NW) load_row(r);
+    if (threadIdx.x < 2 * MD_RING) prog[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        done_upto = -1;
+        loaded_upto = min(MD_RING, H) - 1;
+    }
+    __syncthreads();
+
+    int pa = 0, pb = 255;
+    for (int y = wave; y < H; y += MD_NW) {
+        const int row = f * H + y;
+        const size_t rowoff = (size_t)row * W;
+        const int cnt = k.row_count[row];
+        // rows y +- rad must be resident (this also bounds how far a wave may run ahead of the slowest row)
+        const int need = min(H - 1, y + rad);
+        while (md_lds_load(&loaded_upto) < need) __builtin_amdgcn_s_sleep(2);
+        for (int i = 0; i < cnt; i++) {
+            const HintRec rec = k.rec[rowoff + i];
+            const int x2 = rec.x;
+            const int lowR2 = x2 - (int)ceilf(rec.g) - k.n - m.n_agg_x;
+            const int highR2 = x2 - (int)floorf(rec.g) + k.n + m.n_agg_x;
+            // the only accesses that index column -1 (-> W-1, pyx:113,119,121) belong to patch pixels with xd0 + xw == 0:
+            // such a hint reaches across the whole row and waits for complete rows
+            const int xd0 = x2 - (int)floorf(rec.g);
+            const bool wraps = xd0 >= -k.n && xd0 <= k.n;
+            const int reachL = 2 * k.n + m.n_agg_x;
+            for (int q = max(0, y - dep); q < y; q++) {
+                const int qrow = f * H + q;
+                const int qcnt = k.row_count[qrow];
+                if (qcnt == 0) continue;
+                int p_req = qcnt;
+                if (!wraps) {
+                    const size_t qoff = (size_t)qrow * W;
+                    p_req = 0;
+                    for (int base = 0; base < qcnt; base += 64) { // 1 + index of the last conflicting hint of row q
+                        const int idx = base + lane;
+                        bool conflict = false;
+                        if (idx < qcnt) {
+                            const HintRec r1 = k.rec[qoff + idx];
+                            const int f1 = (int)floorf(r1.g), c1 = (int)ceilf(r1.g);
+                            const int lowR1 = r1.x - c1 - k.n - m.n_agg_x, highR1 = r1.x - f1 + k.n + m.n_agg_x;
+                            const int xd01 = r1.x - f1;
+                            conflict = (abs(r1.x - x2) <= reachL) || (lowR1 <= highR2 && highR1 >= lowR2) ||
+                                       (xd01 >= -k.n && xd01 <= k.n); // a hint that may index column W-1
+                        }
+                        const unsigned long long mk = __builtin_amdgcn_ballot_w64(conflict);
+                        if (mk) p_req = base + 64 - __builtin_clzll(mk);
+                    }
+                }
+                while (md_lds_load(&prog[q & (2 * MD_RING - 1)]) < p_req) __builtin_amdgcn_s_sleep(1);
+            }
+            md_hint(m, mem, f, y, rec, hist, pa, pb);
+            mem.sync();
+            if (lane == 0) md_lds_store(&prog[y & (2 * MD_RING - 1)], i + 1);
+        }
+        // completion token: rows finish in order; the holder retires the oldest ring row and brings in the next one
+        while (md_lds_load(&done_upto) < y - 1) __builtin_amdgcn_s_sleep(2);
+        const int old = y - rad; // no row > y touches rows <= y - rad
+        if (old >= 0) {
+            store_row(old);
+            const int nw = old + MD_RING;
+            if (nw < H) {
+                load_row(nw);
+                if (lane == 0) prog[nw & (2 * MD_RING - 1)] = 0;
+            }
+        }
+        if (y == H - 1)
+            for (int r = max(0, y - rad + 1); r <= y; r++) store_row(r);
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) {
+            if (old >= 0 && old + MD_RING < H) md_lds_store(&loaded_upto, old + MD_RING);
+            md_lds_store(&done_upto, y);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1328,7 +1475,17 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         // rows one hint row can touch: patch radius + vertical half window of the colour search
         const int rad = k.n + m.n_agg_y;
         const size_t lds = (size_t)2 * (2 * rad + 1) * g.W;
-        if (lds <= 60 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
+        const size_t lds_wave = (size_t)2 * MD_RING * g.W;
+        static const int md_wave = getenv("VPPX_MAXDIST_WAVE") ? atoi(getenv("VPPX_MAXDIST_WAVE")) : 1;
+        if (md_wave && k.direction && 2 * rad + 2 <= MD_RING && lds_wave <= 140 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
+            // row wavefront: MD_NW waves per chain
+            static bool attr_set[VPPX_MAX_DEVICES] = {};
+            if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)]) {
+                VPPX_HIP(hipFuncSetAttribute((const void *)maxdist_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+                attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)] = true;
+            }
+            maxdist_wave_kernel<<<dim3(g.B * g.C), 64 * MD_NW, lds_wave, ctx->stream>>>(m, rad);
+        } else if (lds <= 60 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
             maxdist_lds_kernel<<<dim3(g.B * g.C), 64, lds, ctx->stream>>>(m, rad);
         } else {
             maxdist_kernel<<<dim3(g.B * g.C), 64, 0, ctx->stream>>>(m);
