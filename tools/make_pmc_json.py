@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""tools/make_pmc_json.py <tag> <out.json> [--batch B]: per-kernel PMC summary of the passes tools/prof_round.sh left in
+gpurun_out/ (run in the build container, where git knows the commit).  Only launches at the profiled batch size are
+averaged (the bench also makes B=1 calls): they are told apart by the grid size of the dominant kernels.
+FETCH_SIZE is doubled (gfx950 under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md section HBM)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_sha)
+
+
+def passes(tag, name):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{name}", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = re.split(r"[<(]", re.sub(r"^void ", "", r["Kernel_Name"]))[0]
+            acc[k][r["Counter_Name"]].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
+    return acc
+
+
+def big_avg(vals):
+    """average over the launches with the largest grid (the full-batch ones)"""
+    g = max(v[0] for v in vals)
+    sel = [v[1] for v in vals if v[0] == g]
+    return sum(sel) / len(sel), len(sel)
+
+
+def main():
+    tag, out = sys.argv[1], sys.argv[2]
+    batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 32
+    fe, wr, sq = passes(tag, "FETCH_SIZE"), passes(tag, "WRITE_SIZE"), passes(tag, "SQ")
+    kern = {}
+    for k in sorted(set(fe) | set(wr) | set(sq)):
+        d = {}
+        if "FETCH_SIZE" in fe.get(k, {}):
+            d["FETCH_SIZE_KB"], d["launches"] = big_avg(fe[k]["FETCH_SIZE"])
+        if "WRITE_SIZE" in wr.get(k, {}):
+            d["WRITE_SIZE_KB"], _ = big_avg(wr[k]["WRITE_SIZE"])
+        if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
+            d["hbm_GB_per_launch"] = round((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1e3 / 1e9, 3)
+        for c, v in sq.get(k, {}).items():
+            d[c], _ = big_avg(v)
+        if "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"] > 0:
+            for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+                if c in d:
+                    d[c.lower() + "_frac_of_wave_cycles"] = round(d[c] / d["SQ_WAVE_CYCLES"], 3)
+        kern[k] = {a: (round(b, 3 if a.endswith('_cycles') or a.startswith('hbm') else 1) if isinstance(b, float) else b) for a, b in d.items()}
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        commit = None
+    doc = {"note": "rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ set, each its own run) of "
+                   "`python3 bench.py` by tools/prof_round.sh; per-launch averages over the full-batch launches, summed over the "
+                   "chip.  hbm_GB_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB.  SQ_* cycle counters are quad-cycles summed over waves.",
+           "commit": commit, "kernel_source_sha": bench.kernel_source_sha(), "batch": batch, "H": bench.H, "W": bench.W, "D": bench.D,
+           "kernels": kern}
+    json.dump(doc, open(out, "w"), indent=1)
+    for k in ("sgm_paths_kernel", "sum_wta_lr_kernel"):
+        print(k, kern.get(k))
+
+
+if __name__ == "__main__":
+    main()
