@@ -2,7 +2,7 @@
 # Usage (GPU box, repo root): tools/prof_pmc.sh <tag> "<counter list>" [bench args...]
 # One rocprofv3 --pmc pass (own run, kernel-trace only) ; prints per-kernel averages.
 tag=$1; ctrs=$2; shift; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_$tag -o $tag -- python3 bench.py "$@" > gpurun_out/pmc_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, sys, glob, collections
