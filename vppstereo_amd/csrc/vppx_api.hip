@@ -927,6 +927,29 @@ extern "C" int vppx_pfm_decode_dev(vppx_ctx *ctx, const uint8_t *raw, int H, int
     return handoff_pfm_decode(ctx, raw, H, W, channels, little_endian != 0, out);
 }
 
+extern "C" int vppx_png_decode_dev(vppx_ctx *ctx, int n_files, const uint8_t *blob, const int64_t *offsets, int H, int W, int C,
+                                   float scale, float *disp, uint8_t *valid, uint8_t *out_u8, int32_t *status)
+{
+    int rc;
+    VPPX_ENTER(ctx);
+    if (n_files <= 0 || !blob || !offsets || H <= 0 || W <= 0 || (C != 1 && C != 3) || (!disp && !out_u8) || (disp && C != 1)) {
+        vppx_set_error("vppx_png_decode: bad arguments (C must be 1 or 3; the disparity output needs C = 1)");
+        return VPPX_E_INVALID_ARG;
+    }
+    for (int i = 0; i < n_files; i++)
+        if (offsets[i + 1] < offsets[i]) { vppx_set_error("vppx_png_decode: offsets must be non-decreasing"); return VPPX_E_INVALID_ARG; }
+    const size_t raw_stride = ((size_t)H * (1 + (size_t)W * C * 2) + 15) & ~(size_t)15; // up to 16-bit samples
+    u8 *raw;
+    long long *offs_d;
+    int *st_d;
+    if ((rc = ws_get(ctx, WS_PNG_RAW, raw_stride * n_files, &raw))) return rc;
+    if ((rc = ws_get(ctx, WS_PNG_OFFS, (size_t)n_files + 1, &offs_d))) return rc;
+    if (!status && (rc = ws_get(ctx, WS_PNG_STATUS, (size_t)n_files, &st_d))) return rc;
+    ctx->png_offs_host.assign(offsets, offsets + n_files + 1);
+    VPPX_HIP(hipMemcpyAsync(offs_d, ctx->png_offs_host.data(), ((size_t)n_files + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    return handoff_png_decode(ctx, n_files, blob, offs_d, H, W, C, 2, raw, raw_stride, scale, disp, valid, out_u8, status ? status : st_d);
+}
+
 // ---------------------------------------------------------------------------------------
 // occlusion heuristic
 // ---------------------------------------------------------------------------------------

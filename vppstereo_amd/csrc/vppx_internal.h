@@ -89,6 +89,9 @@ enum WsSlot {
     WS_NHINTS,
     WS_HANDOFF_H,    // hints / valid at feature resolution (hand-off kernels)
     WS_HANDOFF_V,
+    WS_PNG_RAW,      // inflated scanlines of a batch of PNG files
+    WS_PNG_OFFS,
+    WS_PNG_STATUS,
     WS_NUM
 };
 
@@ -153,6 +156,7 @@ struct vppx_ctx {
     bool ev_created = false;
     int stage_id[VPPX_MAX_STAGES];
     size_t total_bytes = 0;
+    std::vector<long long> png_offs_host; // kept alive for the asynchronous upload
 };
 
 int ws_reserve(vppx_ctx *ctx, WsSlot s, size_t bytes, void **out);
@@ -250,6 +254,9 @@ int handoff_raft_corr_modulate(vppx_ctx *ctx, float *corr, const float *hints, c
                                int H, int W);
 int handoff_kitti_decode(vppx_ctx *ctx, const uint16_t *png, size_t n, float *disp, u8 *valid);
 int handoff_pfm_decode(vppx_ctx *ctx, const u8 *raw, int H, int W, int channels, int little, float *out);
+// png_kernels.hip
+int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const long long *offs_dev, int H, int W, int C, int max_bpp,
+                       u8 *raw_scratch, size_t raw_stride, float scale, float *disp, u8 *valid, u8 *out_u8, int *status_dev);
 
 // occ_kernels (in vpp_kernels.hip)
 int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,

@@ -193,6 +193,35 @@ class Engine:
         _lib.check(self.lib.vppx_kitti_disp_decode_dev(self.ctx.handle, _ptr(png_u16), png_u16.numel(), _ptr(disp), _ptr(valid)))
         return disp, valid
 
+    def png_decode(self, files, height, width, channels=1, scale=1.0 / 256.0, want="disp"):
+        """PNG FILES (a list of bytes objects, e.g. the KITTI disparity / LiDAR maps of frame_utils.readDispKITTI :66-69)
+        decoded on the device: one upload of the compressed bytes, then chunk walk, inflate and unfiltering in a
+        kernel (one workgroup per file).  want="disp": (disp float32 [n,H,W] = sample * scale, valid uint8);
+        want="u8": uint8 [n,H,W,C] samples of 8-bit gray / RGB images.  Raises on a file the decoder rejects."""
+        import numpy as np
+        torch = self.torch
+        n = len(files)
+        offs = np.zeros(n + 1, np.int64)
+        for i, b in enumerate(files):
+            offs[i + 1] = offs[i] + len(b)
+        blob = torch.frombuffer(bytearray(b"".join(files) + bytes(8)), dtype=torch.uint8).to(self.device)  # padded: aligned word reads
+        status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        disp = valid = out = None
+        if want == "disp":
+            disp = torch.empty((n, height, width), dtype=torch.float32, device=self.device)
+            valid = torch.empty((n, height, width), dtype=torch.uint8, device=self.device)
+        else:
+            out = torch.empty((n, height, width, channels), dtype=torch.uint8, device=self.device)
+        self._bind_stream()
+        _lib.check(self.lib.vppx_png_decode_dev(self.ctx.handle, n, _ptr(blob), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                int(height), int(width), int(channels), float(scale), _ptr(disp), _ptr(valid),
+                                                _ptr(out), _ptr(status)))
+        st = status.cpu().numpy()
+        if st.any():
+            bad = int(np.flatnonzero(st)[0])
+            raise ValueError(f"png_decode: file {bad} rejected with status {int(st[bad])} (see include/vppx.h)")
+        return (disp, valid) if want == "disp" else out
+
     def pfm_decode(self, raw_u8, height, width, channels=1, little_endian=True):
         """PFM payload bytes (device uint8 tensor, header stripped) -> float32 [H,W] or [H,W,3], flipped
         upside-down like frame_utils.readPFM (:34-64)."""
