@@ -35,6 +35,25 @@ def test_param_structs_match_header_defaults():
     assert (p.bilateral_o_xy, p.bilateral_o_i, p.bilateral_th) == (2.0, 1.0, 0.001)
 
 
+def test_unknown_parameter_names_are_rejected():
+    """ctypes would silently create a Python attribute for a misspelt or reference-style keyword."""
+    with pytest.raises(TypeError, match="blending"):
+        _lib.vpp_params(blending=0.4)
+    with pytest.raises(TypeError, match="wsizeAgg_x"):
+        _lib.vpp_params(wsizeAgg_x=64)
+    with pytest.raises(TypeError, match="reserved0"):
+        _lib.rsgm_params(reserved0=1)
+    assert _lib.vpp_params(c=0.25, wsize_agg_x=32).wsize_agg_x == 32
+
+
+def test_calls_without_a_context_fail_with_a_message():
+    lib = _lib.load()
+    null = C.c_void_p()
+    for rc in (lib.vppx_set_stream_legacy(null), lib.vppx_rand_advance(null, 1), lib.vppx_synchronize(null)):
+        assert rc == -7
+        assert b"context is NULL" in lib.vppx_last_error()
+
+
 def _has_gpu():
     try:
         import torch
