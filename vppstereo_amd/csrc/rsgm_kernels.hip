@@ -1293,7 +1293,8 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
     constexpr int TW = T + 2;               // tile row pitch in u16 (2 pad)
     constexpr int TS = D * TW;              // u16 per tile
     constexpr int NWD = (sizeof(IT) == 2) ? NP : NP / 2; // dwords per lane per volume
-    extern __shared__ __attribute__((aligned(16))) u16 ring[]; // [NT][D][TW]
+    extern __shared__ __attribute__((aligned(16))) u16 ring_alloc[]; // T guard elements, then [NT][D][TW]
+    u16 *const ring = ring_alloc + T; // (the FAST gather forms base addresses up to T elements below a tile row's start)
     const int f = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_block;
     const int nrows = (Hp - r0 < rows_per_block) ? Hp - r0 : rows_per_block;
@@ -1387,6 +1388,25 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
             if (xr < Wp) {
                 const int n = (Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1;
                 u32 sr[NP];
+                if constexpr (FAST) {
+                    // S[xr+d][d] for the lane's DPL consecutive d: the column g + d crosses a tile border at most once, so two
+                    // base addresses (this tile / the next, column wrapped) + a compile-time stride of one tile row + 1 serve
+                    // all elements: one select per element, the rest sits in the instruction's offset field
+                    const u32 a0 = (u32)(g + dbase);
+                    u32 sA = r_slot + a0 / T, sB = sA + 1;
+                    sA = sA >= NT ? sA - NT : sA;
+                    sB = sB >= NT ? sB - NT : sB;
+                    sB = sB >= NT ? sB - NT : sB;
+                    const u32 lane_base = (u32)dbase * TW + (a0 % T);
+                    const int RA = (int)(sA * TS + lane_base), RB = (int)(sB * TS + lane_base) - T; // RB >= -T: guard elements
+                    const int e_cross = T - (int)(a0 % T); // first element that lies in the next tile
+#pragma unroll
+                    for (int i = 0; i < NP; i++) {
+                        const u32 lo = ring[(2 * i < e_cross ? RA : RB) + (2 * i) * (TW + 1)];
+                        const u32 hi = ring[(2 * i + 1 < e_cross ? RA : RB) + (2 * i + 1) * (TW + 1)];
+                        sr[i] = lo | (hi << 16);
+                    }
+                } else
 #pragma unroll
                 for (int i = 0; i < NP; i++) {
                     // S[xr+d][d]: stream tile (g+d)/T past the pixel's own (disparities beyond the row end
@@ -1434,7 +1454,7 @@ static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp,
     constexpr int D = 16 * DPL;
     constexpr int NR = (T + D - 2) / T + 1;
     constexpr int NT = NR + (SPARE ? 1 : 0);
-    const size_t lds = (size_t)NT * D * (T + 2) * sizeof(u16);
+    const size_t lds = ((size_t)NT * D * (T + 2) + T) * sizeof(u16);
     static bool attr_set[VPPX_MAX_DEVICES] = {}; // function attributes are per device
     const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
     if (!attr_set[dv]) {
