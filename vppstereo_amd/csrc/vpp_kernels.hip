@@ -1273,6 +1273,7 @@ __global__ void __launch_bounds__(64) maxdist_lds_kernel(MdK m, int rad)
 // ---------------------------------------------------------------------------------------
 #define MD_NW 16
 #define MD_RING 32
+#define MD_PRE_ROWS 4 // rows above with precomputed wait targets (dep = 2n + agg_y/2: 3 for the defaults)
 struct MemRing {
     u8 *sl, *sr; // [MD_RING][W]
     int W;
@@ -1290,6 +1291,7 @@ __device__ __forceinline__ void md_lds_store(int *p, int v) { __hip_atomic_store
 __global__ void __launch_bounds__(64 * MD_NW) maxdist_wave_kernel(MdK m, int rad)
 {
     __shared__ u32 hist_all[MD_NW][256];
+    __shared__ u16 preq_all[MD_NW][MD_PRE_ROWS * 64]; // wait targets of the wave's current row, per row above
     __shared__ int prog[2 * MD_RING]; // hints completed in row r (slot r % 32: a slot is recycled 32 rows later, long after its last reader)
     __shared__ int done_upto;       // rows 0..done_upto are complete (completion token passes in row order)
     __shared__ int loaded_upto;     // rows 0..loaded_upto are (or have been) resident in the ring
@@ -1305,6 +1307,7 @@ __global__ void __launch_bounds__(64 * MD_NW) maxdist_wave_kernel(MdK m, int rad
     mem.sr = md_rows + (size_t)MD_RING * W;
     mem.W = W;
     u32 *hist = hist_all[wave];
+    u16 *preq = preq_all[wave];
     const int dep = k.n + rad;
     auto load_row = [&](int r) { // by one wave
         const int o = mem.off(r);
@@ -1337,8 +1340,49 @@ __global__ void __launch_bounds__(64 * MD_NW) maxdist_wave_kernel(MdK m, int rad
         // rows y +- rad must be resident (this also bounds how far a wave may run ahead of the slowest row)
         const int need = min(H - 1, y + rad);
         while (md_lds_load(&loaded_upto) < need) __builtin_amdgcn_s_sleep(2);
+        // Rows with at most 64 hints (and neighbours with at most 64): the wait targets of every hint are worked out
+        // before the row starts -- lane k holds hint k of a row above, the row's own hints are broadcast one by one
+        // and each conflict test is one ballot -- so that the hint loop itself touches no global memory for them.
+        const int q_lo = max(0, y - dep);
+        bool pre = cnt <= 64 && (y - q_lo) <= MD_PRE_ROWS;
+        for (int q = q_lo; q < y; q++) pre = pre && k.row_count[f * H + q] <= 64;
+        if (pre && cnt > 0) {
+            const HintRec mine = lane < cnt ? k.rec[rowoff + lane] : HintRec{0, 0.f, 0u, 0u};
+            for (int q = q_lo; q < y; q++) {
+                const int qcnt = k.row_count[f * H + q];
+                const HintRec r1 = lane < qcnt ? k.rec[(size_t)(f * H + q) * W + lane] : HintRec{0, 0.f, 0u, 0u};
+                const int f1 = (int)floorf(r1.g), c1 = (int)ceilf(r1.g);
+                const int lowR1 = r1.x - c1 - k.n - m.n_agg_x, highR1 = r1.x - f1 + k.n + m.n_agg_x;
+                const bool wrap1 = (r1.x - f1) >= -k.n && (r1.x - f1) <= k.n;
+                for (int i = 0; i < cnt; i++) {
+                    const int x2 = __builtin_amdgcn_readlane(mine.x, i);
+                    const float g2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.g), i));
+                    const int lowR2 = x2 - (int)ceilf(g2) - k.n - m.n_agg_x, highR2 = x2 - (int)floorf(g2) + k.n + m.n_agg_x;
+                    const int xd0 = x2 - (int)floorf(g2);
+                    int p_req = qcnt;
+                    if (!(xd0 >= -k.n && xd0 <= k.n)) {
+                        const bool conflict = lane < qcnt && ((abs(r1.x - x2) <= 2 * k.n + m.n_agg_x) ||
+                                                              (lowR1 <= highR2 && highR1 >= lowR2) || wrap1);
+                        const unsigned long long mk = __builtin_amdgcn_ballot_w64(conflict);
+                        p_req = mk ? 64 - __builtin_clzll(mk) : 0;
+                    }
+                    if (lane == 0) preq[(q - q_lo) * 64 + i] = (u16)p_req;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
         for (int i = 0; i < cnt; i++) {
             const HintRec rec = k.rec[rowoff + i];
+            if (pre) {
+                for (int q = q_lo; q < y; q++) {
+                    const int p_req = preq[(q - q_lo) * 64 + i];
+                    while (md_lds_load(&prog[q & (2 * MD_RING - 1)]) < p_req) __builtin_amdgcn_s_sleep(1);
+                }
+                md_hint(m, mem, f, y, rec, hist, pa, pb);
+                mem.sync();
+                if (lane == 0) md_lds_store(&prog[y & (2 * MD_RING - 1)], i + 1);
+                continue;
+            }
             const int x2 = rec.x;
             const int lowR2 = x2 - (int)ceilf(rec.g) - k.n - m.n_agg_x;
             const int highR2 = x2 - (int)floorf(rec.g) + k.n + m.n_agg_x;
@@ -1477,11 +1521,11 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         const size_t lds = (size_t)2 * (2 * rad + 1) * g.W;
         const size_t lds_wave = (size_t)2 * MD_RING * g.W;
         static const int md_wave = getenv("VPPX_MAXDIST_WAVE") ? atoi(getenv("VPPX_MAXDIST_WAVE")) : 1;
-        if (md_wave && k.direction && 2 * rad + 2 <= MD_RING && lds_wave <= 140 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
+        if (md_wave && k.direction && 2 * rad + 2 <= MD_RING && lds_wave <= 132 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
             // row wavefront: MD_NW waves per chain
             static bool attr_set[VPPX_MAX_DEVICES] = {};
             if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)]) {
-                VPPX_HIP(hipFuncSetAttribute((const void *)maxdist_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+                VPPX_HIP(hipFuncSetAttribute((const void *)maxdist_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
                 attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)] = true;
             }
             maxdist_wave_kernel<<<dim3(g.B * g.C), 64 * MD_NW, lds_wave, ctx->stream>>>(m, rad);
