@@ -1,6 +1,7 @@
 """GPU parity of the optional execution variants (environment knobs read at context creation):
 the band-marching vertical kernel (VPPX_VERT=1), other lanes-per-pixel layouts (VPPX_GW) and
-sub-stream splitting (VPPX_SUBSTREAMS).  Each variant runs in a fresh process."""
+sub-stream splitting (VPPX_SUBSTREAMS), the general sum / WTA decision code (VPPX_SUM_FAST=0) and the one-wave-per-chain
+maxDistance kernels (VPPX_MAXDIST_WAVE=0).  Each variant runs in a fresh process."""
 import os
 import subprocess
 import sys
@@ -34,7 +35,7 @@ print("VARIANT_OK", eng.uses_vert())
 
 
 @pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_GW="16"), dict(VPPX_GW="4"), dict(VPPX_GW="8"), dict(VPPX_SUBSTREAMS="2"),
-                                 dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2")])
+                                 dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2"), dict(VPPX_SUM_FAST="0")])
 def test_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)
@@ -42,3 +43,14 @@ def test_variant_matches_oracle(env):
     assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     if env.get("VPPX_VERT") == "1":
         assert "VARIANT_OK True" in r.stdout
+
+
+@pytest.mark.parametrize("env", [dict(VPPX_MAXDIST_WAVE="0"), dict(VPPX_MAXDIST_GLOBAL="1")])
+def test_maxdist_one_wave_kernels_still_match_the_golden_cases(env):
+    """The row-wavefront kernel is the default; the LDS-ring and in-place one-wave kernels stay as fall-backs
+    (x-descending scans, frames too wide for the LDS ring) and must keep passing the same golden / anchor tests."""
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_vpp.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "maxdist"], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
