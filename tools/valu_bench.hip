@@ -156,6 +156,13 @@ DEF_KERNEL(ds_read_u16, "ds_read_u16 %0, %8\n ds_read_u16 %1, %8 offset:2\n ds_r
     "ds_read_u16 %4, %8 offset:8\n ds_read_u16 %5, %8 offset:10\n ds_read_u16 %6, %8 offset:12\n ds_read_u16 %7, %8 offset:14\n s_waitcnt lgkmcnt(0)\n")
 DEF_KERNEL(ds_read_b32, "ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:256\n ds_read_b32 %2, %8 offset:512\n ds_read_b32 %3, %8 offset:768\n"
     "ds_read_b32 %4, %8 offset:1024\n ds_read_b32 %5, %8 offset:1280\n ds_read_b32 %6, %8 offset:1536\n ds_read_b32 %7, %8 offset:1792\n s_waitcnt lgkmcnt(0)\n")
+// gfx950 additions
+DEF_KERNEL(pk_minimum3_f16, L4("v_pk_minimum3_f16"))
+DEF_KERNEL(pk_maximum3_f16, L4("v_pk_maximum3_f16"))
+DEF_KERNEL(minimum3_f32, L4("v_minimum3_f32"))
+DEF_KERNEL(bitop3_b32, "v_bitop3_b32 %0, %0, %8, %9 bitop3:0x96\n v_bitop3_b32 %1, %1, %8, %9 bitop3:0x96\n v_bitop3_b32 %2, %2, %8, %9 bitop3:0x96\n v_bitop3_b32 %3, %3, %8, %9 bitop3:0x96\n"
+    "v_bitop3_b32 %4, %4, %8, %9 bitop3:0x96\n v_bitop3_b32 %5, %5, %8, %9 bitop3:0x96\n v_bitop3_b32 %6, %6, %8, %9 bitop3:0x96\n v_bitop3_b32 %7, %7, %8, %9 bitop3:0x96\n")
+DEF_KERNEL(pk_min_u16_opsel, L3S("v_pk_min_u16", "op_sel:[1,0] op_sel_hi:[0,1]"))
 // mixed: the min-plus inner sequence of one pair (alignbit, pk_min, pk_add, pk_min, pk_min, pk_sub) on 8 chains
 #define MIXLINE(R) \
     "v_alignbit_b32 " R ", " R ", %8, 16\n v_pk_min_u16 " R ", " R ", %9\n v_pk_add_u16 " R ", " R ", %8 clamp\n" \
@@ -181,7 +188,7 @@ int main(int argc, char **argv)
                     E(pk_min_f16), E(pk_max_f16), E(pk_add_f16), E(pk_mul_f16), E(pk_fma_f16), E(pk_min_i16), E(pk_add_i16),
                     E(min3_f16), E(min3_u16), E(xor_e64), E(add_u32_e64), E(min_u16_e64), E(xor_dpp), E(min_u16_dpp),
                     E(add_u32_dpp_shr), E(cndmask_sgpr), E(cmp_cnd), E(readlane), E(ds_write_b16), E(ds_write_b32), E(ds_read_u16),
-                    E(ds_read_b32)};
+                    E(ds_read_b32), E(pk_minimum3_f16), E(pk_maximum3_f16), E(minimum3_f32), E(bitop3_b32), E(pk_min_u16_opsel)};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int ncu = prop.multiProcessorCount;

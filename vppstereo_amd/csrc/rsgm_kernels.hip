@@ -147,6 +147,12 @@ template <int NW>
 __device__ __forceinline__ void store_words_nt(u32 *p, const u32 (&w)[NW])
 {
     int i = 0;
+    if constexpr (NW == 3) { // one global_store_dwordx3: the lanes' 12-byte pieces tile whole lines (2 + 1 would leave holes)
+        typedef u32 u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+        const u32x3a t = {w[0], w[1], w[2]};
+        __builtin_nontemporal_store(t, (u32x3a *)p);
+        return;
+    }
 #pragma unroll
     for (; i + 4 <= NW; i += 4) {
         u32x4 t = {w[i], w[i + 1], w[i + 2], w[i + 3]};
@@ -383,6 +389,16 @@ __device__ __forceinline__ u32 grp_min_u32(u32 v)
     return v;
 }
 
+// Three-way packed minimum of u16 pairs whose values are all < 0x7C00: non-negative finite f16 bit patterns order
+// like the integers they spell (denormals included: the kernels run with f16 denormals on, the HIP default), so
+// gfx950's v_pk_minimum3_f16 is a v_pk_min3_u16 for them -- one half-rate VOP3P op instead of two.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pk_min3_small(u32 a, u32 b, u32 c)
+{
+    const f16x2 x = __builtin_bit_cast(f16x2, a), y = __builtin_bit_cast(f16x2, b), z = __builtin_bit_cast(f16x2, c);
+    return __builtin_bit_cast(u32, __builtin_elementwise_minimum(__builtin_elementwise_minimum(x, y), z));
+}
+
 // One min-plus step for NP packed pairs per lane.  `first`/`last` tell whether this lane holds
 // the lowest / highest disparities of its pixel (d-1 of the first and d+1 of the last do not
 // exist: 0xFFFF sentinel).  The work is written stage by stage across all pairs: gfx950 needs a
@@ -394,11 +410,14 @@ template <int NP, bool EXACT, int GW, bool FUSE>
 __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], const u32 (&X0)[NP], const u32 (&X1)[NP],
                                            u32 P1pk, u32 P2pk, u32 &minpk, const u32 (&inact)[NP], bool first, bool last)
 {
-    u32 left_in = dpp_keep<0x111>(0xFFFFFFFFu, L[NP - 1]); // row_shr:1 : lane-1's last pair
-    u32 right_in = dpp_keep<0x101>(0xFFFFFFFFu, L[0]);     // row_shl:1 : lane+1's first pair
+    // FUSE: the three-way minimum below reads the words as f16 bit patterns, so "no neighbour" must stay a finite
+    // f16 after P1 has been added: 0x3FFF instead of 0xFFFF (every real value of the byte variant is < 0x300)
+    constexpr u32 NONE = FUSE ? 0x3FFF3FFFu : 0xFFFFFFFFu;
+    u32 left_in = dpp_keep<0x111>(NONE, L[NP - 1]); // row_shr:1 : lane-1's last pair
+    u32 right_in = dpp_keep<0x101>(NONE, L[0]);     // row_shl:1 : lane+1's first pair
     if (GW < 16) {
-        left_in = first ? 0xFFFFFFFFu : left_in;
-        right_in = last ? 0xFFFFFFFFu : right_in;
+        left_in = first ? NONE : left_in;
+        right_in = last ? NONE : right_in;
     }
     // FUSE = byte volumes: every value stays far below 2^16, so the packed adds / subtracts cannot carry or borrow
     // across the halves and plain 32-bit v_add_u32 / v_sub_u32 do the same job at twice the issue rate of the
@@ -414,13 +433,20 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], con
     for (int i = 0; i < NP; i++) m[i] = pk_min(al[i], al[i + 1]);
 #pragma unroll
     for (int i = 0; i < NP; i++) m[i] = FUSE ? m[i] + P1pk : pk_adds(m[i], P1pk);
-#pragma unroll
-    for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], L[i]);
-#pragma unroll
-    for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], t2);
     if (FUSE) {
-        // m += popc(x0) rides on v_bcnt_u32_b32's accumulator operand, the high half on v_lshl_add_u32;
-        // the empty asm keeps the two adds from being re-associated into (lshl_or + add)
+#pragma unroll
+        for (int i = 0; i < NP; i++) m[i] = pk_min3_small(m[i], L[i], t2);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], L[i]);
+#pragma unroll
+        for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], t2);
+    }
+    if (FUSE) {
+        // m += popc(x0) rides on v_bcnt_u32_b32's accumulator operand, the high half on a shift + add (hipcc emits
+        // v_lshlrev_b32 + v_add_u32 rather than one v_lshl_add_u32; forcing the latter through inline asm saved 0.4 % at
+        // B=32 and cost 13 % at B=1, where the scheduler could no longer interleave the chains: left to the compiler).
+        // The empty asm keeps the two adds from being re-associated into (lshl_or + add).
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             u32 t = (u32)__popc(X0[i]) + m[i];
@@ -437,11 +463,22 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], con
         if (!EXACT) m[i] |= inact[i]; // slots d >= D stay at the 0xFFFF sentinel (never the minimum)
         L[i] = m[i];
     }
-    // min over this lane's pairs as a balanced tree, then across the pixel's lanes
+    // min over this lane's pairs as a balanced tree (three-way where the values allow it), then across the pixel's lanes
+    if (FUSE) {
 #pragma unroll
-    for (int w = 1; w < NP; w <<= 1)
+        for (int n = NP; n > 1; n = (n + 2) / 3)
 #pragma unroll
-        for (int i = 0; i + w < NP; i += 2 * w) m[i] = pk_min(m[i], m[i + w]);
+            for (int i = 0; 3 * i < n; i++) {
+                if (3 * i + 2 < n) m[i] = pk_min3_small(m[3 * i], m[3 * i + 1], m[3 * i + 2]);
+                else if (3 * i + 1 < n) m[i] = pk_min(m[3 * i], m[3 * i + 1]);
+                else m[i] = m[3 * i];
+            }
+    } else {
+#pragma unroll
+        for (int w = 1; w < NP; w <<= 1)
+#pragma unroll
+            for (int i = 0; i + w < NP; i += 2 * w) m[i] = pk_min(m[i], m[i + w]);
+    }
     u32 mm = min(m[0] & 0xFFFFu, m[0] >> 16);
     mm = grp_min_u32<GW>(mm);
     minpk = pk_splat(mm);
@@ -502,9 +539,12 @@ __device__ __forceinline__ void step_costs(const StepIn<DPL, FROM_DSI> &s, int l
     }
 }
 
+// LDS words per wave of the store transposition below: 8 pixels x 192 bytes + their 8 pixel indices
+#define TR_WORDS (384 + 8)
+
 template <int DPL, bool EXACT, typename OT>
 __device__ __forceinline__ void store_step(OT *out_f, int pixl, int D, int dbase, const u32 (&L)[DPL / 2],
-                                           const u32 (&inact)[DPL / 2])
+                                           const u32 (&inact)[DPL / 2], u32 *tr = nullptr)
 {
     constexpr int NP = DPL / 2;
     const u32 off = (u32)pixl * (u32)D + (u32)dbase;
@@ -522,6 +562,32 @@ __device__ __forceinline__ void store_step(OT *out_f, int pixl, int D, int dbase
         u32 bw[NP / 2];
 #pragma unroll
         for (int i = 0; i + 1 < NP; i += 2) bw[i / 2] = __builtin_amdgcn_perm(L[i + 1], L[i], 0x06040200u);
+        if constexpr (DPL == 24) {
+            if (tr) {
+                // 8 lanes x 24 disparities per pixel: a lane's 24 bytes are not a power of two, so its two stores
+                // (16 + 8 bytes at a 24-byte stride) each leave byte holes in every 128-byte line they touch, and the
+                // streaming (nt) write path sends such partial lines on as they are (store-only timing of this launch:
+                // 10.6 ms with the holes, 4.7 ms without).  Transpose through LDS so that each store instruction
+                // covers whole contiguous lines: 64 x 16 bytes = bytes [0, 1024) of the wave's 8 x 192, then
+                // 64 x 8 bytes = bytes [1024, 1536).  The pixels of a wave need not be neighbours in memory (rows of a
+                // horizontal line block, wrap of a diagonal), so their indices travel through LDS as well.
+                // One wave, in-order LDS queue: no barrier.
+                const int lane = threadIdx.x & 63;
+                u32x2 *wp = (u32x2 *)(tr + lane * 6);
+                wp[0] = u32x2{bw[0], bw[1]};
+                wp[1] = u32x2{bw[2], bw[3]};
+                wp[2] = u32x2{bw[4], bw[5]};
+                tr[384 + (lane >> 3)] = (u32)pixl;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const u32x4 a = *(const u32x4 *)(tr + lane * 4);
+                const u32x2 b = *(const u32x2 *)(tr + 256 + lane * 2);
+                const u32 pa = tr[384 + lane / 12], pb = tr[384 + (128 + lane) / 24];
+                __builtin_nontemporal_store(a, (u32x4 *)((u8 *)out_f + (pa * (u32)D + (u32)(lane % 12) * 16u)));
+                __builtin_nontemporal_store(b, (u32x2 *)((u8 *)out_f + (pb * (u32)D + (u32)((128 + lane) % 24) * 8u)));
+                return;
+            }
+        }
         store_words_nt<NP / 2>((u32 *)((u8 *)out_f + off), bw);
     }
 }
@@ -581,7 +647,8 @@ __device__ __forceinline__ void line_step(LineState<DPL> &st, const StepIn<DPL, 
     // bookkeeping assume the smaller number of younger operations, so every wait for a prefetched load also drained
     // the stores issued after it (vmcnt(0) on the loop back edge: the wave idled for a store round trip per step).
     // The lanes of a clamped, inactive line hold exactly the values of the last line and may store them again.
-    if (CAN_FUSE || line_active) store_step<DPL, EXACT, OT>(out_f, pixl, D, dbase, st.L, inact);
+    u32 *tr = (CAN_FUSE && DPL == 24 && GW == 8) ? (u32 *)s_lut + 256 + (threadIdx.x >> 6) * TR_WORDS : nullptr;
+    if (CAN_FUSE || line_active) store_step<DPL, EXACT, OT>(out_f, pixl, D, dbase, st.L, inact, tr);
     st.prevI = in.I;
 }
 
@@ -645,7 +712,9 @@ template <int GW, int DPL, bool EXACT, bool FROM_DSI, typename OT>
 __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
 {
     constexpr int LPB = 256 / GW; // scan lines per block
-    __shared__ u32 s_lut[256];
+    // P2 table + (byte variant of the 8 x 24 layout) the waves' store transposition buffers
+    constexpr bool TR = !FROM_DSI && EXACT && sizeof(OT) == 1 && DPL == 24 && GW == 8;
+    __shared__ __attribute__((aligned(16))) u32 s_lut[256 + (TR ? 4 * TR_WORDS : 0)];
     s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
     __syncthreads();
 
