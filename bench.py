@@ -15,10 +15,12 @@ per GPU); the only exchange is the final gather of the disparity maps to rank 0,
 this process has made any GPU call, and exits with the first non-zero rank status.
 
 One JSON line is printed by rank 0.  Extra objects:
-  roofline     -- dominant kernel (8-path aggregation): algorithmic bytes per launch (10 B/cell of SURVEY
-                  8d's 16 B/cell) / average launch duration measured with hipEvents
-                  on the launch stream, vs 8 TB/s; next to it the PMC view of the same kernel (real HBM
-                  bytes, VALU issue time) from the committed profile of THIS kernel source (else null).
+  roofline     -- dominant kernel (the fused vertical aggregation kernel, 6 of the 8 paths; the 8-path kernel
+                  when that layout runs): algorithmic bytes per launch (SURVEY 8d's 10 B/cell for the 8-path
+                  aggregation, pro rata for the paths the launch carries) / average launch
+                  duration measured with hipEvents on the launch stream, vs 8 TB/s; next to it the PMC view of
+                  the same kernel (real HBM bytes, VALU issue time) from the committed profile of THIS kernel
+                  source (else null).
   b1           -- the literal cfg-2 "single pair": latency of one frame per call.
   cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference's own rSGM natives
                   are not in its tree) timed on this box's host cores on a bounded sample, rank 0, N=1.
@@ -224,7 +226,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_view(agg_frames, kernel_ms):
+def pmc_view(agg_frames, kernel_ms, kernel="sgm_paths_kernel"):
     """PMC numbers of the aggregation kernel from the committed profile, or None when the profile was taken from
     other kernel sources / another batch size."""
     try:
@@ -235,7 +237,7 @@ def pmc_view(agg_frames, kernel_ms):
     if pmc.get("kernel_source_sha") != kernel_source_sha() or pmc.get("batch") != agg_frames or \
             (pmc.get("H"), pmc.get("W"), pmc.get("D")) != (H, W, D):
         return None
-    k = pmc.get("kernels", {}).get("sgm_paths_kernel")
+    k = pmc.get("kernels", {}).get(kernel)
     if not k:
         return None
     out = dict(k)
@@ -391,14 +393,21 @@ def run_rank(args):
         # ---- dominant kernel, measured live with hipEvents on its own launch stream ----------
         # average over the launches made INSIDE the timed region (event pairs on the launch stream, ring of 64)
         agg_ms, agg_n = eng.agg_kernel_ms(args.steps)
-        agg_ms_b2b = eng.time_aggregate(iters=max(3, min(10, args.steps)))  # same kernel re-launched back to back
+        layout = eng.uses_vert()   # 0: one launch, eight line-parallel paths; 3: W/E launch + the fused vertical kernel
+        fused = layout == 3
+        # same kernel re-launched back to back (fused layout: its part of the aggregation only)
+        agg_ms_b2b = eng.time_aggregate_part(2, max(3, min(10, args.steps))) if fused else eng.time_aggregate(iters=max(3, min(10, args.steps)))
         if agg_n == 0 or agg_ms <= 0:   # graph replays carry no event pairs
             agg_ms = agg_ms_b2b
         agg_frames = eng.time_aggregate_frames()  # frames per launch (the batch is split over sub-streams)
         Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
         cells_launch = agg_frames * Hp * Wp * D
-        achieved = cells_launch * AGG_BYTES_PER_CELL / (agg_ms * 1e-3) / 1e9
-        pmc = pmc_view(agg_frames, agg_ms)
+        # SURVEY 8d prices the 8-path aggregation at 10 B/cell; the fused vertical kernel carries 6 of the 8 paths
+        agg_bytes = AGG_BYTES_PER_CELL * (6.0 / 8.0 if fused else 1.0)
+        dom_kernel = "sgm_vert3_kernel" if fused else "sgm_paths_kernel"
+        achieved = cells_launch * agg_bytes / (agg_ms * 1e-3) / 1e9
+        pmc = pmc_view(agg_frames, agg_ms, dom_kernel)
+        we_ms = eng.time_aggregate_part(1, 3) if fused else None
         # the same step without the occlusion mask (the reference's default, test.py --maskocc off): rank-local, no collectives
         other = None
         if world == 1:
@@ -438,19 +447,22 @@ def run_rank(args):
             "ranks": {"launched": args.gpus, "seen": dist.get_world_size() if world > 1 else 1,
                       "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
                       "ms_per_step_per_rank": [round(x, 3) for x in rank_ms]},
-            "roofline": {"bound": "valu", "kernel": "sgm_paths_kernel (8-path aggregation)",
+            "roofline": {"bound": "valu",
+                         "kernel": ("sgm_vert3_kernel (N, NW, NE and S, SW, SE fused three at a time: 6 of the 8 aggregation paths)"
+                                    if fused else "sgm_paths_kernel (8-path aggregation)"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None,
                          "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; null unless the committed profile "
                                          "was taken from these kernel sources at this batch size)",
                          "pmc": pmc,
-                         "algorithmic_GB_per_launch": round(cells_launch * AGG_BYTES_PER_CELL / 1e9, 3),
+                         "algorithmic_GB_per_launch": round(cells_launch * agg_bytes / 1e9, 3),
                          "kernel_ms": round(agg_ms, 4), "kernel_launches_timed": agg_n,
-                         "kernel_ms_back_to_back": round(agg_ms_b2b, 4), "bytes_per_cell": AGG_BYTES_PER_CELL,
+                         "kernel_ms_back_to_back": round(agg_ms_b2b, 4), "bytes_per_cell": agg_bytes,
+                         "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": round(we_ms, 4)} if fused else None),
                          "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,
-                         "note": "HBM-roofline convention of SURVEY 8d; the kernel itself is issue-bound (VALU + store issue, "
-                                 "DESIGN section 6), hence bound = valu"},
+                         "note": "HBM-roofline convention of SURVEY 8d (10 B/cell for the 8-path aggregation, pro rata for the paths "
+                                 "a launch carries); the kernel itself is issue-bound (DESIGN section 6), hence bound = valu"},
             "pipeline_roofline": {"bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,
                                   "achieved_GBps": round(pipeline_gbs, 1),
                                   "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4)},

@@ -1,5 +1,6 @@
 """GPU parity of the optional execution variants (environment knobs read at context creation):
-the band-marching vertical kernel (VPPX_VERT=1), other lanes-per-pixel layouts (VPPX_GW) and
+the aggregation layouts (VPPX_VERT: 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel; the default
+picks 3 from 8 frames per launch on), other lanes-per-pixel layouts (VPPX_GW) and
 sub-stream splitting (VPPX_SUBSTREAMS), the general sum / WTA decision code (VPPX_SUM_FAST=0) and the one-wave-per-chain
 maxDistance kernels (VPPX_MAXDIST_WAVE=0).  Each variant runs in a fresh process."""
 import os
@@ -17,7 +18,7 @@ sys.path.insert(0, %r)
 import oracle, synth
 from vppstereo_amd.engine import Engine
 eng = Engine()
-for (B, H, W, D) in ((1, 24, 300, 256), (4, 50, 150, 192), (8, 40, 96, 64), (2, 70, 81, 128)):
+for (B, H, W, D) in ((1, 24, 300, 256), (4, 50, 150, 192), (8, 40, 96, 64), (2, 70, 81, 128), (8, 21, 230, 192)):
     b = synth.make_batch(B, H, W, D, 0.05, seed=B * H)
     dev = eng.device
     lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev); rv = torch.empty_like(lv)
@@ -30,19 +31,26 @@ for (B, H, W, D) in ((1, 24, 300, 256), (4, 50, 150, 192), (8, 40, 96, 64), (2, 
         lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
         assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), (B, f)
         assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D), out[f]), (B, H, W, D, f)
-print("VARIANT_OK", eng.uses_vert())
+print("VARIANT_OK", int(eng.uses_vert()))   # how the LAST shape (8 frames, D = 192) was aggregated
 """ % ROOT
 
 
-@pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_GW="16"), dict(VPPX_GW="4"), dict(VPPX_GW="8"), dict(VPPX_SUBSTREAMS="2"),
-                                 dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2"), dict(VPPX_SUM_FAST="0")])
+@pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_VERT="0"), dict(VPPX_VERT="3"), dict(VPPX_GW="16"), dict(VPPX_GW="4"),
+                                 dict(VPPX_GW="8"), dict(VPPX_SUBSTREAMS="2"), dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2"),
+                                 dict(VPPX_VERT="3", VPPX_SUBSTREAMS="2"), dict(VPPX_SUM_FAST="0"), dict()])
 def test_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
-    if env.get("VPPX_VERT") == "1":
-        assert "VARIANT_OK True" in r.stdout
+    # 0 = eight line-parallel paths, 1 = band marching, 3 = fused vertical kernel (the default from 8 frames on)
+    want = {"0": 0, "1": 1, "3": 3}.get(env.get("VPPX_VERT"), 3)
+    if env.get("VPPX_SUBSTREAMS") == "2" and env.get("VPPX_VERT") == "3":
+        want = 3    # 2 x 4 frames: still a multiple of four
+    elif env.get("VPPX_SUBSTREAMS") == "2" and "VPPX_VERT" not in env:
+        want = None  # 4 frames per sub-stream: below the default's threshold
+    if want is not None:
+        assert "VARIANT_OK %d" % want in r.stdout, r.stdout[-300:]
 
 
 @pytest.mark.parametrize("env", [dict(VPPX_MAXDIST_WAVE="0"), dict(VPPX_MAXDIST_GLOBAL="1")])

@@ -406,7 +406,8 @@ __device__ __forceinline__ u32 pk_min3_small(u32 a, u32 b, u32 c)
 // are kept side by side instead of one dependent chain after the other.
 // FUSE: the matching cost is added with v_bcnt_u32_b32's free accumulator (plain add); only
 // used by the byte-volume variant, where nothing can saturate.  X0/X1 = cl ^ cr words.
-template <int NP, bool EXACT, int GW, bool FUSE>
+// FUSE + PRE: same small-value arithmetic, but the packed costs C are given.
+template <int NP, bool EXACT, int GW, bool FUSE, bool PRE = false>
 __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], const u32 (&X0)[NP], const u32 (&X1)[NP],
                                            u32 P1pk, u32 P2pk, u32 &minpk, const u32 (&inact)[NP], bool first, bool last)
 {
@@ -442,7 +443,10 @@ __device__ __forceinline__ void sgm_update(u32 (&L)[NP], const u32 (&C)[NP], con
 #pragma unroll
         for (int i = 0; i < NP; i++) m[i] = pk_min(m[i], t2);
     }
-    if (FUSE) {
+    if (FUSE && PRE) { // small-value arithmetic, the packed costs are given (shared by several paths of a pixel)
+#pragma unroll
+        for (int i = 0; i < NP; i++) m[i] += C[i];
+    } else if (FUSE) {
         // m += popc(x0) rides on v_bcnt_u32_b32's accumulator operand, the high half on a shift + add (hipcc emits
         // v_lshlrev_b32 + v_add_u32 rather than one v_lshl_add_u32; forcing the latter through inline asm saved 0.4 % at
         // B=32 and cost 13 % at B=1, where the scheduler could no longer interleave the chains: left to the compiler).
@@ -1104,6 +1108,288 @@ int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, i
 }
 
 // ---------------------------------------------------------------------------------------
+// Vertical / diagonal paths three at a time with the state in registers (round 2; D = 192 byte variant).
+// One launch runs two passes per frame: pass 0 walks the rows top-down and carries N, NW, NE; pass 1 walks
+// bottom-up and carries S, SW, SE.  A wave owns 8 neighbouring columns (8 lanes x 24 disparities per pixel, the
+// layout of sgm_paths_kernel<8, 24>) for the whole pass and keeps the three paths' L_r of the previous row in
+// VGPRs.  Per row: the census costs are formed ONCE and shared by the three min-plus updates, the straight path
+// updates in place, the two diagonal states move one pixel sideways (ds_bpermute inside the wave; the wave's edge
+// pixel comes from the neighbouring wave through a small global record served by the XCD's L2), and ONE byte per
+// cell (the sum of the three paths, <= 3 * (24 + P2max) <= 255) is stored: 2 volumes instead of 6, and the
+// sum/WTA kernel reads 4 volumes instead of 8.
+// All waves of a (frame, pass) group advance in lock step: every row needs both neighbours' previous row.  The
+// hand-off has no flag and no drain: every dword of an edge record carries the row number in the bits the values
+// leave free (values < 1024 per half), the reader polls the record itself (sc1 loads: L1 bypassed, `tools/
+// pingpong_bench.hip`: 0.4 us per hand-off inside an XCD) until all its dwords show the row it waits for.  The
+// records are zeroed before every launch.  Blocks of a group are consecutive in one XCD's dispatch order
+// (blockIdx & 7 = XCD) and blocks start in index order, so every block a resident block waits for is resident or
+// next in line; polls are bounded all the same.
+// ---------------------------------------------------------------------------------------
+struct Vert3Args {
+    const u8 *gray;
+    const u32 *cl;
+    const u32 *cr;
+    const u16 *p2lut;
+    u8 *sv;     // [2 passes][B][Hp][Wp][D]
+    u32 *xbuf;  // [2B groups][nwv][V3_RING rows][2 directions][8 lanes][V3_XW] edge records
+    unsigned *err; // host-visible word, set when a wave gave up waiting for a neighbour (results void)
+    int B, Hp, Wp, p1;
+    int nwv, nbg; // waves / blocks per group
+    size_t vol_elems;
+};
+#define V3_XW 16 // dwords per lane of an edge record: 12 pairs, the packed minimum, 3 pad
+#define V3_SPIN_LIMIT (1 << 16)
+// Rows of edge records kept per wave.  A wave may write the record of row t+1 while a neighbour is still reading the
+// one of row t-1 (the NW record of a row is published before the NE record of the row before has been consumed), so
+// the slot reused must be at least three rows old: a ring of four.
+#define V3_RING 4
+#define V3_TAGMASK 0xFC00FC00u
+
+__device__ __forceinline__ u32x4 ld_sc1_x4(const u32 *p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32 ld_sc1(const u32 *p)
+{
+    u32 v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// The edge records of row t-1 (tag word T): group-0 lanes read the left wave's NW record, group-7 lanes the right
+// wave's NE record (a lane reads at most one).  v3_edges_issue starts the loads, v3_edges_complete waits for them
+// (draining everything older in the memory pipe: next row's operands, last row's stores), checks the tags, polls
+// again while a record is not there yet, and returns the 13 dwords with the tags stripped (zeros for lanes that read
+// nothing).  The straight path's update runs between the two.
+struct V3Edge {
+    u32x4 a, b, c;
+    u32 m;
+};
+__device__ __forceinline__ void v3_edges_issue(const u32 *ep, bool want, V3Edge &r)
+{
+    if (want) {
+        r.a = ld_sc1_x4(ep);
+        r.b = ld_sc1_x4(ep + 4);
+        r.c = ld_sc1_x4(ep + 8);
+        r.m = ld_sc1(ep + 12);
+    }
+}
+__device__ __forceinline__ void v3_edges_complete(const u32 *ep, bool want, u32 T, V3Edge &r, u32 (&e)[13], bool &dead)
+{
+    int spins = dead ? V3_SPIN_LIMIT - 2 : 0; // a wave that gave up once does not wait again (results are void anyway)
+    for (;;) {
+        bool ok = true;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.m)::"memory");
+        if (want) {
+            e[0] = r.a.x; e[1] = r.a.y; e[2] = r.a.z; e[3] = r.a.w;
+            e[4] = r.b.x; e[5] = r.b.y; e[6] = r.b.z; e[7] = r.b.w;
+            e[8] = r.c.x; e[9] = r.c.y; e[10] = r.c.z; e[11] = r.c.w;
+            e[12] = r.m;
+            u32 bad = 0;
+#pragma unroll
+            for (int i = 0; i < 13; i++) bad |= (e[i] ^ T);
+            ok = (bad & V3_TAGMASK) == 0;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        if (++spins >= V3_SPIN_LIMIT) {
+            dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v3_edges_issue(ep, want, r);
+    }
+#pragma unroll
+    for (int i = 0; i < 13; i++) e[i] = want ? (e[i] & ~V3_TAGMASK) : 0u;
+}
+
+__global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
+{
+    constexpr int DPL = 24, NP = 12, D = 192;
+    __shared__ __attribute__((aligned(16))) u32 s_lut[256 + 4 * TR_WORDS];
+    s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
+    __syncthreads();
+    const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
+    const int group = (jb / a.nbg) * 8 + xcd, bi = jb % a.nbg;
+    const int f = group >> 1, pass = group & 1;
+    const int wv = bi * 4 + (int)(threadIdx.x >> 6);
+    if (wv >= a.nwv) return;
+    const int lane = threadIdx.x & 63, g = lane >> 3, lg = lane & 7;
+    const int x = wv * 8 + g, dbase = DPL * lg;
+    const int Wp = a.Wp, Hp = a.Hp;
+    const size_t fpix = (size_t)f * Hp * Wp;
+    const u8 *gray_f = a.gray + fpix;
+    const u32 *cl_f = a.cl + fpix;
+    const u32 *cr_f = a.cr + fpix;
+    u8 *sv_f = a.sv + (size_t)pass * a.vol_elems + fpix * D;
+    u32 *tr = s_lut + 256 + (threadIdx.x >> 6) * TR_WORDS;
+    const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
+    const bool first = lg == 0, last = lg == 7;
+    const bool has_left = wv > 0, has_right = wv + 1 < a.nwv;
+    constexpr int REC = V3_RING * 2 * 8 * V3_XW; // dwords per wave: [row & 3][direction][lane]
+    bool dead = false;
+    u32 *xb_own = a.xbuf + ((size_t)group * a.nwv + wv) * REC;
+    // group-0 lanes take the left wave's NW edge (direction 0), group-7 lanes the right wave's NE edge (direction 1)
+    const bool edge_lane = (g == 0 && has_left) || (g == 7 && has_right);
+    const u32 *xb_in = a.xbuf + ((size_t)group * a.nwv + (g == 0 ? (has_left ? wv - 1 : wv) : (has_right ? wv + 1 : wv))) * REC +
+                       ((g == 0 ? 0 : 1) * 8 + lg) * V3_XW;
+    const int bp_left = ((lane - 8) & 63) << 2, bp_right = ((lane + 8) & 63) << 2;
+    const bool masked = wv * 8 < D - 1; // some d > x in this wave: InvalidDispCost
+    u32 inact[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) inact[i] = 0;
+
+    u32 L0[NP], L1[NP], L2[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) L0[i] = L1[i] = L2[i] = 0;
+    u32 mn0 = 0, mn1 = 0, mn2 = 0;
+    int prevI = 0;
+    const int dy = pass == 0 ? 1 : -1;
+    int y = pass == 0 ? 0 : Hp - 1;
+    const int xl = x > 0 ? x - 1 : 0, xr = x < Wp - 1 ? x + 1 : Wp - 1;
+    StepIn<DPL, false> A;
+    load_step<DPL, true, false>(A, gray_f, cl_f, cr_f, nullptr, y * Wp + x, D, dbase, inact);
+    int Ipl = 0, Ipr = 0;
+    // the row's bytes leave one row late (right after the next row's poll), so that no wait of this wave ever has a
+    // young volume store in front of it
+    u32x4 pend_a = {0, 0, 0, 0};
+    u32x2 pend_b = {0, 0};
+    u32 pend_oa = ((u32)(y * Wp + wv * 8) * (u32)D) + (u32)lane * 16u, pend_ob = pend_oa; // harmless first store (rewritten)
+    for (int t = 0; t < Hp; t++, y += dy) {
+        const int pixl = y * Wp + x;
+        // ---- costs of this row, once for the three paths
+        u32 C[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const u32 c0 = __popc(A.clv ^ A.w[DPL - 1 - 2 * i]);
+            const u32 c1 = __popc(A.clv ^ A.w[DPL - 2 - 2 * i]);
+            C[i] = (c1 << 16) | c0;
+        }
+        if (masked) {
+            const int lim = x - dbase;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const u32 lo = (2 * i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
+                const u32 hi = (2 * i + 1 <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
+                C[i] = lo | (hi << 16);
+            }
+        }
+        const int I = A.I;
+        const u32 P2a = s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)prevI, 0u)];
+        const u32 P2b = s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)Ipl, 0u)];
+        const u32 P2c = s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)Ipr, 0u)];
+        // tag words of the records read now (row t-1) and written now (row t): row + 1 in bits 10-15 / 26-31
+        const u32 Tin = (((u32)t & 63u) << 10) | (((u32)t >> 6) << 26);
+        const u32 Tout = (((u32)(t + 1) & 63u) << 10) | (((u32)(t + 1) >> 6) << 26);
+        const int par_in = (t - 1) & (V3_RING - 1), par_out = t & (V3_RING - 1);
+        // ---- the neighbours' edges of the previous row: one round trip to L2, covered by the straight path's update
+        V3Edge er;
+        er.a = er.b = er.c = u32x4{0, 0, 0, 0};
+        er.m = 0;
+        const u32 *ep = xb_in + par_in * (2 * 8 * V3_XW);
+        if (t > 0) v3_edges_issue(ep, edge_lane, er);
+        // ---- straight path: needs nobody else's state
+        sgm_update<NP, true, 8, true, true>(L0, C, C, C, P1pk, P2a, mn0, inact, first, last);
+        {
+            u32 e[13];
+            if (t > 0) v3_edges_complete(ep, edge_lane, Tin, er, e, dead);
+            else {
+#pragma unroll
+                for (int i = 0; i < 13; i++) e[i] = 0;
+            }
+            // the two diagonal states move one pixel sideways: inside the wave by ds_bpermute, at its ends from the records
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const u32 s1 = (u32)__builtin_amdgcn_ds_bpermute(bp_left, (int)L1[i]);
+                const u32 s2 = (u32)__builtin_amdgcn_ds_bpermute(bp_right, (int)L2[i]);
+                L1[i] = (g == 0) ? e[i] : s1;
+                L2[i] = (g == 7) ? e[i] : s2;
+            }
+            const u32 m1 = (u32)__builtin_amdgcn_ds_bpermute(bp_left, (int)mn1);
+            const u32 m2 = (u32)__builtin_amdgcn_ds_bpermute(bp_right, (int)mn2);
+            mn1 = (g == 0) ? e[12] : m1;
+            mn2 = (g == 7) ? e[12] : m2;
+        }
+        // ---- last row's bytes (everything older has just been drained: this store has a whole row to complete)
+        __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
+        __builtin_nontemporal_store(pend_b, (u32x2 *)(sv_f + pend_ob));
+        // ---- NW / SW, then NE / SE; each publishes its edge pixel as soon as it is known
+        sgm_update<NP, true, 8, true, true>(L1, C, C, C, P1pk, P2b, mn1, inact, first, last);
+        if (t + 1 < Hp && g == 7 && has_right) { // the last pixel's state goes to the right wave
+            u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (0 * 8 + lg) * V3_XW;
+#pragma unroll
+            for (int i = 0; i < NP; i += 4)
+                *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1] | Tout, L1[i + 2] | Tout, L1[i + 3] | Tout};
+            q[NP] = mn1 | Tout;
+        }
+        sgm_update<NP, true, 8, true, true>(L2, C, C, C, P1pk, P2c, mn2, inact, first, last);
+        if (t + 1 < Hp && g == 0 && has_left) { // the first pixel's state goes to the left wave
+            u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (1 * 8 + lg) * V3_XW;
+#pragma unroll
+            for (int i = 0; i < NP; i += 4)
+                *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1] | Tout, L2[i + 2] | Tout, L2[i + 3] | Tout};
+            q[NP] = mn2 | Tout;
+        }
+        // ---- operands of the next row.  Issued this late on purpose: in flight during the updates they cost 26 more
+        // live VGPRs (156 instead of 127, 3 waves per SIMD instead of 4); the shorter distance to their use is covered
+        // by the fourth wave
+        {
+            const int yn = (t + 1 < Hp) ? y + dy : y;
+            load_step<DPL, true, false>(A, gray_f, cl_f, cr_f, nullptr, yn * Wp + x, D, dbase, inact);
+            Ipl = gray_f[y * Wp + xl];
+            Ipr = gray_f[y * Wp + xr];
+        }
+        // ---- one byte per cell: the three paths summed, transposed through LDS into whole-line pieces (store_step)
+        {
+            u32 bw[NP / 2];
+#pragma unroll
+            for (int i = 0; i + 1 < NP; i += 2)
+                bw[i / 2] = __builtin_amdgcn_perm(L0[i + 1] + L1[i + 1] + L2[i + 1], L0[i] + L1[i] + L2[i], 0x06040200u);
+            u32x2 *wp = (u32x2 *)(tr + lane * 6);
+            wp[0] = u32x2{bw[0], bw[1]};
+            wp[1] = u32x2{bw[2], bw[3]};
+            wp[2] = u32x2{bw[4], bw[5]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            pend_a = *(const u32x4 *)(tr + lane * 4);
+            pend_b = *(const u32x2 *)(tr + 256 + lane * 2);
+            // the wave's 8 pixels are neighbours in memory: bytes [0, 1024) and [1024, 1536) of its 8 x 192
+            const u32 base = (u32)(y * Wp + wv * 8) * (u32)D;
+            pend_oa = base + (u32)lane * 16u;
+            pend_ob = base + 1024u + (u32)lane * 8u;
+        }
+        prevI = I;
+    }
+    __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
+    __builtin_nontemporal_store(pend_b, (u32x2 *)(sv_f + pend_ob));
+    if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
+{
+    // edge values and their packed minimum must stay below 1024 (tag bits), the three-path sum below 256
+    return D == 192 && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095;
+}
+size_t rsgm_vert3_xbuf_bytes(int B, int Wp) { return (size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * V3_XW) * sizeof(u32); }
+
+int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
+                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err)
+{
+    Vert3Args a;
+    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.xbuf = xbuf; a.err = err;
+    a.B = B; a.Hp = Hp; a.Wp = Wp; a.p1 = p1;
+    a.nwv = Wp / 8;
+    a.nbg = (a.nwv + 3) / 4;
+    a.vol_elems = (size_t)B * Hp * Wp * D;
+    VPPX_HIP(hipMemsetAsync(xbuf, 0, rsgm_vert3_xbuf_bytes(B, Wp), stream)); // no record of an earlier launch may match
+    sgm_vert3_kernel<<<dim3((unsigned)(2 * B * a.nbg)), 256, 0, stream>>>(a);
+    VPPX_CHECK_LAUNCH();
+    (void)ctx; (void)D;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // S = sum of the 8 path volumes, fused with the left WTA + uniqueness (rsgm.py:141) and the
 // equiangular sub-pixel refinement (rsgm.py:142).  One 16-lane row per pixel.
 // ---------------------------------------------------------------------------------------
@@ -1400,17 +1686,27 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
             u32 acc[NP];
 #pragma unroll
             for (int i = 0; i < NP; i++) acc[i] = 0;
-            if constexpr (SW4 && sizeof(IT) == 1 && (NV == 8 || NV == 4)) {
+            if constexpr (SW4 && sizeof(IT) == 1 && NV == 4) {
+                // fused-path layout: two single-path volumes (W, E; their byte sum cannot carry) and two volumes that
+                // hold three summed paths each (<= 255): widen the three operands, plain 32-bit adds on the u16 pairs
+#pragma unroll
+                for (int i = 0; i < NP / 2; i++) {
+                    const u32 ab = w[0][i] + w[1][i];
+                    acc[2 * i] = __builtin_amdgcn_perm(ab, ab, 0x0c010c00u) + __builtin_amdgcn_perm(w[2][i], w[2][i], 0x0c010c00u) +
+                                 __builtin_amdgcn_perm(w[3][i], w[3][i], 0x0c010c00u);
+                    acc[2 * i + 1] = __builtin_amdgcn_perm(ab, ab, 0x0c030c02u) + __builtin_amdgcn_perm(w[2][i], w[2][i], 0x0c030c02u) +
+                                     __builtin_amdgcn_perm(w[3][i], w[3][i], 0x0c030c02u);
+                }
+            } else if constexpr (SW4 && sizeof(IT) == 1 && NV == 8) {
 #pragma unroll
                 for (int i = 0; i < NP / 2; i++) {
                     const u32 ab = (w[0][i] + w[1][i]) + (w[2][i] + w[3][i]);
                     acc[2 * i] = __builtin_amdgcn_perm(ab, ab, 0x0c010c00u);
                     acc[2 * i + 1] = __builtin_amdgcn_perm(ab, ab, 0x0c030c02u);
-                    if constexpr (NV == 8) { // sums stay below 2^16: plain 32-bit adds (full rate) on the pairs
-                        const u32 cd = (w[4][i] + w[5][i]) + (w[6][i] + w[7][i]);
-                        acc[2 * i] += __builtin_amdgcn_perm(cd, cd, 0x0c010c00u);
-                        acc[2 * i + 1] += __builtin_amdgcn_perm(cd, cd, 0x0c030c02u);
-                    }
+                    // sums stay below 2^16: plain 32-bit adds (full rate) on the pairs
+                    const u32 cd = (w[4][i] + w[5][i]) + (w[6][i] + w[7][i]);
+                    acc[2 * i] += __builtin_amdgcn_perm(cd, cd, 0x0c010c00u);
+                    acc[2 * i + 1] += __builtin_amdgcn_perm(cd, cd, 0x0c030c02u);
                 }
             } else {
 #pragma unroll
@@ -1588,9 +1884,9 @@ static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
                            float *disp_l, float *disp_r, u32 fu, int sub, int max_path_value)
 {
-    // 8 single-path volumes: two groups of four are added as bytes; 4 volumes (band-marching variant): they hold
-    // sums of up to three paths, so all of them together must fit a byte
-    const bool sw4 = elem_bytes == 1 && max_path_value > 0 && (nvol == 8 ? 4 * max_path_value <= 255 : 8 * max_path_value <= 255);
+    // byte arithmetic in the sum: 8 single-path volumes are added four at a time as packed bytes; 4 volumes (fused
+    // vertical paths: W, E, and two three-path sums) add W + E as bytes and widen the rest
+    const bool sw4 = elem_bytes == 1 && max_path_value > 0 && (nvol == 8 ? 4 * max_path_value <= 255 : 3 * max_path_value <= 255);
     if ((D != 64 && D != 128 && D != 192 && D != 256) || (nvol != 8 && nvol != 4)) return 1; // caller falls back
     VolPtrs vp;
     for (int i = 0; i < 8; i++) vp.v[i] = i < nvol ? vols[i] : nullptr;

@@ -112,7 +112,10 @@ struct vppx_ctx {
     vppx_ctx *sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sub_done[4] = {nullptr, nullptr, nullptr, nullptr};
     bool is_child = false;
-    int use_vert = 0;              // VPPX_VERT=1: band-marching kernel for the 6 non-horizontal paths (experimental, slower)
+    int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
+    int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
+    unsigned *vert3_err = nullptr; // pinned host word the fused vertical kernel sets when a wave gave up waiting
+    bool vert3_broken = false;     // set once vert3_err was seen: the context stays on the line-parallel kernel
     DevBuf ws[WS_NUM];
     std::string devname;
     // libc-like stream state of the single-frame scans
@@ -209,6 +212,10 @@ int rsgm_launch_guided_dsi(vppx_ctx *ctx, const RsgmGeom &g, u16 *dsi, const flo
 int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
                       const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes, int dir_mask);
 // band-marching vertical/diagonal paths (3 summed paths per pass, one byte per cell)
+bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2);
+size_t rsgm_vert3_xbuf_bytes(int B, int Wp);
+int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
+                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err);
 bool rsgm_vert_supported(int D, int maxp2);
 size_t rsgm_vert_state_bytes(int B, int Wp, int D);
 size_t rsgm_vert_min_elems(int B, int Wp);

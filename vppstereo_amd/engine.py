@@ -265,7 +265,9 @@ class Engine:
         return float(ms.value)
 
     def uses_vert(self):
-        return bool(self.lib.vppx_uses_vert(self.ctx.handle))
+        """Aggregation layout of the last call: 0 = eight line-parallel paths, 1 = band marching (experiment),
+        3 = W/E line-parallel + the fused three-path vertical kernel (default from 8 frames per launch on)."""
+        return int(self.lib.vppx_uses_vert(self.ctx.handle))
 
     def enable_stage_timing(self, on=True):
         _lib.check(self.lib.vppx_enable_stage_timing(self.ctx.handle, int(bool(on))))
