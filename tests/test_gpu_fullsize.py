@@ -63,6 +63,32 @@ def test_cfg3_kitti_375x1242_d192_full_size(eng):
     _fused_vs_oracle(eng, 375, 1242, 192, 0.05, seed=103)
 
 
+@pytest.mark.parametrize("H,W,p,n_oracle", [(540, 960, 0.03, 2), (375, 1242, 0.05, 1)])
+def test_batched_fused_vertical_layout_full_size(eng, H, W, p, n_oracle, monkeypatch):
+    """Batches of 8+ frames aggregate N/NW/NE and S/SW/SE with the fused lock-step kernel (sgm_vert3_kernel; one frame
+    per call, as in the tests above, takes the eight line-parallel paths).  At full size: every frame of a batch of 8
+    equals the 8-path layout bit for bit, and the first `n_oracle` frames equal the CPU oracle."""
+    import torch
+    from vppstereo_amd.engine import Engine
+    B, D = 8, 192
+    b = synth.make_batch(B, H, W, D, p, seed=300 + H)
+    args = [_dev(eng, b[k]) for k in ("left", "right", "hints")]
+    out = eng.vpp_rsgm(*args, seed=5, rsgm_kw=dict(dmax=D, subpixel=1))
+    torch.cuda.synchronize()
+    assert eng.uses_vert() == 3
+    monkeypatch.setenv("VPPX_VERT", "0")
+    eng8 = Engine()
+    out8 = eng8.vpp_rsgm(*args, seed=5, rsgm_kw=dict(dmax=D, subpixel=1))
+    torch.cuda.synchronize()
+    assert eng8.uses_vert() == 0
+    assert torch.equal(out, out8)
+    got = out.cpu().numpy()
+    for f in range(n_oracle):
+        oracle.init_rand(5 + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
+        assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D, subpixel=True), got[f]), f
+
+
 def test_cfg5_1536x2048_d256_full_size(eng):
     """configs[4]: 1536x2048, 1 % hints, D = 256 (0.8 G cells; ~40 s of oracle time)."""
     _fused_vs_oracle(eng, 1536, 2048, 256, 0.01, seed=105, with_occ=False)

@@ -861,7 +861,10 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
         if (gw_override == 4) return launch_paths_t<4, 48>(ctx, a, B, from_dsi, elem_bytes);
         // fewer than 8 frames do not fill the chip with 8 lanes per pixel (1920 waves per frame): twice the
         // waves at 7 waves/SIMD win below that (B=1: 0.45 vs 0.60 ms), 8 x 24 wins from B=16 on (-5 %)
-        if (gw_override == 16 || (gw_override != 8 && B < 8)) return launch_paths_t<16, 12>(ctx, a, B, from_dsi, elem_bytes);
+        // the W/E-only launch of the fused layout has 4352 8-lane waves for 4096 slots: its second round is a tail as long
+        // as the first; twice the waves at 7 per SIMD pack better (B=32: 2.34 -> 2.06 ms)
+        if (gw_override == 16 || (gw_override != 8 && (B < 8 || a.dir_mask == 0x11)))
+            return launch_paths_t<16, 12>(ctx, a, B, from_dsi, elem_bytes);
         return launch_paths_t<8, 24>(ctx, a, B, from_dsi, elem_bytes);
     }
     if (gw_override == 8) return launch_paths_t<8, 32>(ctx, a, B, from_dsi, elem_bytes);
@@ -1664,7 +1667,9 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
     int r_row = r0, r_k = 0, r_slot = 0;
     // operands are fetched two rounds ahead into a ping-pong register set: the loads of round j+2
     // are issued before round j is summed, so two rounds of HBM latency are covered
-    u32 wa[NV][NWD], wb[NV][NWD];
+    // four volumes (fused vertical layout) leave room for a third operand set: three rounds of HBM latency covered
+    constexpr int PF = (NV == 4 && sizeof(IT) == 1) ? 3 : 2;
+    u32 wa[NV][NWD], wb[NV][NWD], wc[PF == 3 ? NV : 1][PF == 3 ? NWD : 1];
     auto fetch = [&](u32 (&w)[NV][NWD]) {
         int x = T * f_k + g;
         x = x < Wp ? x : Wp - 1;
@@ -1723,7 +1728,7 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
                     }
                 }
             }
-            if (j + 2 < total) fetch(w); // this register set is free again
+            if (j + PF < total) fetch(w); // this register set is free again
             if (x < Wp) { // uniform per 16-lane group
                 u16 *t = ring + l_slot * TS + g;
 #pragma unroll
@@ -1807,9 +1812,18 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
     };
     fetch(wa);
     if (total > 1) fetch(wb);
-    for (int j = 0; j < total + NR - 1; j += 2) {
-        round(j, wa);
-        if (j + 1 < total + NR - 1) round(j + 1, wb);
+    if constexpr (PF == 3) {
+        if (total > 2) fetch(wc);
+        for (int j = 0; j < total + NR - 1; j += 3) {
+            round(j, wa);
+            if (j + 1 < total + NR - 1) round(j + 1, wb);
+            if (j + 2 < total + NR - 1) round(j + 2, wc);
+        }
+    } else {
+        for (int j = 0; j < total + NR - 1; j += 2) {
+            round(j, wa);
+            if (j + 1 < total + NR - 1) round(j + 1, wb);
+        }
     }
 }
 
