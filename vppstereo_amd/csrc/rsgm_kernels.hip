@@ -1121,8 +1121,8 @@ int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, i
 // cell (the sum of the three paths, <= 3 * (24 + P2max) <= 255) is stored: 2 volumes instead of 6, and the
 // sum/WTA kernel reads 4 volumes instead of 8.
 // All waves of a (frame, pass) group advance in lock step: every row needs both neighbours' previous row.  The
-// hand-off has no flag and no drain: every dword of an edge record carries the row number in the bits the values
-// leave free (values < 1024 per half), the reader polls the record itself (sc1 loads: L1 bypassed, `tools/
+// hand-off has no flag and no drain: every 16-byte piece of an edge record carries the row number in the bits the
+// values leave free (values < 1024 per half), the reader polls the record itself (sc1 loads: L1 bypassed, `tools/
 // pingpong_bench.hip`: 0.4 us per hand-off inside an XCD) until all its dwords show the row it waits for.  The
 // records are zeroed before every launch.  Blocks of a group are consecutive in one XCD's dispatch order
 // (blockIdx & 7 = XCD) and blocks start in index order, so every block a resident block waits for is resident or
@@ -1148,63 +1148,43 @@ struct Vert3Args {
 #define V3_RING 4
 #define V3_TAGMASK 0xFC00FC00u
 
-__device__ __forceinline__ u32x4 ld_sc1_x4(const u32 *p)
-{
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ u32 ld_sc1(const u32 *p)
-{
-    u32 v;
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
 // The edge records of row t-1 (tag word T): group-0 lanes read the left wave's NW record, group-7 lanes the right
-// wave's NE record (a lane reads at most one).  v3_edges_issue starts the loads, v3_edges_complete waits for them
-// (draining everything older in the memory pipe: next row's operands, last row's stores), checks the tags, polls
-// again while a record is not there yet, and returns the 13 dwords with the tags stripped (zeros for lanes that read
-// nothing).  The straight path's update runs between the two.
+// wave's NE record (a lane reads at most one; lanes without a record read a record of zeros).  Buffer loads with the
+// sc1 bit (device scope: L1 bypassed, served by the XCD's L2) that the compiler can see, so it keeps their results
+// where they land and waits for them where they are used: v3_edges_issue starts them, the straight path's update
+// runs, v3_edges_complete checks the tags, polls again while a record is not there yet, and strips the tags.
+// One tag per 16-byte piece (its first dword; a lane's aligned 16-byte store and 16-byte load are single requests
+// to one cache line, so a piece is seen whole or not at all) and one on the minimum.
 struct V3Edge {
     u32x4 a, b, c;
     u32 m;
 };
-__device__ __forceinline__ void v3_edges_issue(const u32 *ep, bool want, V3Edge &r)
+#define V3_SC1 16 // cache-policy operand of the buffer load builtins: bit 4 = sc1 on gfx940+
+__device__ __forceinline__ void v3_edges_issue(__amdgpu_buffer_rsrc_t xr, int off, V3Edge &r)
 {
-    if (want) {
-        r.a = ld_sc1_x4(ep);
-        r.b = ld_sc1_x4(ep + 4);
-        r.c = ld_sc1_x4(ep + 8);
-        r.m = ld_sc1(ep + 12);
-    }
+    r.a = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, V3_SC1);
+    r.b = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, V3_SC1);
+    r.c = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 32, 0, V3_SC1);
+    r.m = __builtin_amdgcn_raw_buffer_load_b32(xr, off + 48, 0, V3_SC1);
 }
-__device__ __forceinline__ void v3_edges_complete(const u32 *ep, bool want, u32 T, V3Edge &r, u32 (&e)[13], bool &dead)
+__device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int off, bool want, u32 T, V3Edge &r, bool &dead)
 {
     int spins = dead ? V3_SPIN_LIMIT - 2 : 0; // a wave that gave up once does not wait again (results are void anyway)
     for (;;) {
-        bool ok = true;
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.m)::"memory");
-        if (want) {
-            e[0] = r.a.x; e[1] = r.a.y; e[2] = r.a.z; e[3] = r.a.w;
-            e[4] = r.b.x; e[5] = r.b.y; e[6] = r.b.z; e[7] = r.b.w;
-            e[8] = r.c.x; e[9] = r.c.y; e[10] = r.c.z; e[11] = r.c.w;
-            e[12] = r.m;
-            u32 bad = 0;
-#pragma unroll
-            for (int i = 0; i < 13; i++) bad |= (e[i] ^ T);
-            ok = (bad & V3_TAGMASK) == 0;
-        }
+        const u32 bad = ((r.a.x ^ T) | (r.b.x ^ T) | (r.c.x ^ T) | (r.m ^ T)) & V3_TAGMASK;
+        const bool ok = !want || bad == 0;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         if (++spins >= V3_SPIN_LIMIT) {
             dead = true;
             break;
         }
         __builtin_amdgcn_s_sleep(1);
-        v3_edges_issue(ep, want, r);
+        v3_edges_issue(xr, off, r);
     }
-#pragma unroll
-    for (int i = 0; i < 13; i++) e[i] = want ? (e[i] & ~V3_TAGMASK) : 0u;
+    r.a.x &= ~V3_TAGMASK;
+    r.b.x &= ~V3_TAGMASK;
+    r.c.x &= ~V3_TAGMASK;
+    r.m &= ~V3_TAGMASK;
 }
 
 __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
@@ -1235,8 +1215,11 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     u32 *xb_own = a.xbuf + ((size_t)group * a.nwv + wv) * REC;
     // group-0 lanes take the left wave's NW edge (direction 0), group-7 lanes the right wave's NE edge (direction 1)
     const bool edge_lane = (g == 0 && has_left) || (g == 7 && has_right);
-    const u32 *xb_in = a.xbuf + ((size_t)group * a.nwv + (g == 0 ? (has_left ? wv - 1 : wv) : (has_right ? wv + 1 : wv))) * REC +
-                       ((g == 0 ? 0 : 1) * 8 + lg) * V3_XW;
+    // (byte offsets into the record buffer, read through a buffer resource)
+    const int xb_in_off = (int)(((size_t)group * a.nwv + (g == 0 ? (has_left ? wv - 1 : wv) : (has_right ? wv + 1 : wv))) * REC +
+                                ((g == 0 ? 0 : 1) * 8 + lg) * V3_XW) * 4;
+    const int zero_off = (int)((size_t)2 * a.B * a.nwv * REC) * 4; // one record nobody writes
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, zero_off + V3_XW * 4, 0x00020000);
     const int bp_left = ((lane - 8) & 63) << 2, bp_right = ((lane + 8) & 63) << 2;
     const bool masked = wv * 8 < D - 1; // some d > x in this wave: InvalidDispCost
     u32 inact[NP];
@@ -1287,20 +1270,17 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         const u32 Tout = (((u32)(t + 1) & 63u) << 10) | (((u32)(t + 1) >> 6) << 26);
         const int par_in = (t - 1) & (V3_RING - 1), par_out = t & (V3_RING - 1);
         // ---- the neighbours' edges of the previous row: one round trip to L2, covered by the straight path's update
+        // lanes that take no record (and everybody in the first row) keep zeros: the path starts / restarts there
         V3Edge er;
-        er.a = er.b = er.c = u32x4{0, 0, 0, 0};
-        er.m = 0;
-        const u32 *ep = xb_in + par_in * (2 * 8 * V3_XW);
-        if (t > 0) v3_edges_issue(ep, edge_lane, er);
+        const bool want = edge_lane && t > 0;
+        const int eoff = want ? xb_in_off + par_in * (2 * 8 * V3_XW * 4) : zero_off;
+        v3_edges_issue(xrsrc, eoff, er);
         // ---- straight path: needs nobody else's state
         sgm_update<NP, true, 8, true, true>(L0, C, C, C, P1pk, P2a, mn0, inact, first, last);
+        v3_edges_complete(xrsrc, eoff, want, Tin, er, dead);
         {
-            u32 e[13];
-            if (t > 0) v3_edges_complete(ep, edge_lane, Tin, er, e, dead);
-            else {
-#pragma unroll
-                for (int i = 0; i < 13; i++) e[i] = 0;
-            }
+            const u32 e[13] = {er.a.x, er.a.y, er.a.z, er.a.w, er.b.x, er.b.y, er.b.z, er.b.w,
+                               er.c.x, er.c.y, er.c.z, er.c.w, er.m};
             // the two diagonal states move one pixel sideways: inside the wave by ds_bpermute, at its ends from the records
 #pragma unroll
             for (int i = 0; i < NP; i++) {
@@ -1322,16 +1302,14 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         if (t + 1 < Hp && g == 7 && has_right) { // the last pixel's state goes to the right wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (0 * 8 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4)
-                *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1] | Tout, L1[i + 2] | Tout, L1[i + 3] | Tout};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], L1[i + 3]};
             q[NP] = mn1 | Tout;
         }
         sgm_update<NP, true, 8, true, true>(L2, C, C, C, P1pk, P2c, mn2, inact, first, last);
         if (t + 1 < Hp && g == 0 && has_left) { // the first pixel's state goes to the left wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (1 * 8 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4)
-                *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1] | Tout, L2[i + 2] | Tout, L2[i + 3] | Tout};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], L2[i + 3]};
             q[NP] = mn2 | Tout;
         }
         // ---- operands of the next row.  Issued this late on purpose: in flight during the updates they cost 26 more
@@ -1374,7 +1352,10 @@ bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
     // edge values and their packed minimum must stay below 1024 (tag bits), the three-path sum below 256
     return D == 192 && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095;
 }
-size_t rsgm_vert3_xbuf_bytes(int B, int Wp) { return (size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * V3_XW) * sizeof(u32); }
+size_t rsgm_vert3_xbuf_bytes(int B, int Wp)
+{
+    return ((size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * V3_XW) + V3_XW) * sizeof(u32); // + the record of zeros
+}
 
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err)
