@@ -1128,6 +1128,51 @@ int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, i
 // (blockIdx & 7 = XCD) and blocks start in index order, so every block a resident block waits for is resident or
 // next in line; polls are bounded all the same.
 // ---------------------------------------------------------------------------------------
+// Min-plus step of the fused kernel: small-value arithmetic with given packed costs like sgm_update<.., FUSE, PRE>,
+// but pair i of a lane holds the disparities (dbase + i, dbase + NP + i) instead of two neighbours.  The d-1 / d+1
+// operands of BOTH halves of pair i are then simply pairs i-1 and i+1: no v_alignbit per pair, only one at each end
+// of the lane (d-1 of the first half comes from the previous lane, d+1 of the last from the next).
+template <int NP, int GW>
+__device__ __forceinline__ void sgm_update_split(u32 (&L)[NP], const u32 (&C)[NP], u32 P1pk, u32 P2pk, u32 &minpk, bool first,
+                                                 bool last)
+{
+    constexpr u32 NONE = 0x3FFF3FFFu;
+    u32 prev = dpp_keep<0x111>(NONE, L[NP - 1]); // row_shr:1 : lane-1's last pair (its high half is d = dbase - 1)
+    u32 next = dpp_keep<0x101>(NONE, L[0]);      // row_shl:1 : lane+1's first pair (its low half is d = dbase + 2 NP)
+    if (GW < 16) {
+        prev = first ? NONE : prev;
+        next = last ? NONE : next;
+    }
+    const u32 below0 = __builtin_amdgcn_alignbit(L[NP - 1], prev, 16); // {d = dbase - 1, d = dbase + NP - 1}
+    const u32 above_last = __builtin_amdgcn_alignbit(next, L[0], 16);  // {d = dbase + NP, d = dbase + 2 NP}
+    const u32 t2 = minpk + P2pk;
+    u32 m[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_min(i == 0 ? below0 : L[i - 1], i == NP - 1 ? above_last : L[i + 1]);
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] += P1pk;
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_min3_small(m[i], L[i], t2);
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] += C[i];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        m[i] -= minpk;
+        L[i] = m[i];
+    }
+#pragma unroll
+    for (int n = NP; n > 1; n = (n + 2) / 3)
+#pragma unroll
+        for (int i = 0; 3 * i < n; i++) {
+            if (3 * i + 2 < n) m[i] = pk_min3_small(m[3 * i], m[3 * i + 1], m[3 * i + 2]);
+            else if (3 * i + 1 < n) m[i] = pk_min(m[3 * i], m[3 * i + 1]);
+            else m[i] = m[3 * i];
+        }
+    u32 mm = min(m[0] & 0xFFFFu, m[0] >> 16);
+    mm = grp_min_u32<GW>(mm);
+    minpk = pk_splat(mm);
+}
+
 struct Vert3Args {
     const u8 *gray;
     const u32 *cl;
@@ -1245,19 +1290,20 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     for (int t = 0; t < Hp; t++, y += dy) {
         const int pixl = y * Wp + x;
         // ---- costs of this row, once for the three paths
+        // (pair i of a lane = disparities dbase + i and dbase + 12 + i: sgm_update_split)
         u32 C[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const u32 c0 = __popc(A.clv ^ A.w[DPL - 1 - 2 * i]);
-            const u32 c1 = __popc(A.clv ^ A.w[DPL - 2 - 2 * i]);
+            const u32 c0 = __popc(A.clv ^ A.w[DPL - 1 - i]);
+            const u32 c1 = __popc(A.clv ^ A.w[DPL - 1 - NP - i]);
             C[i] = (c1 << 16) | c0;
         }
         if (masked) {
             const int lim = x - dbase;
 #pragma unroll
             for (int i = 0; i < NP; i++) {
-                const u32 lo = (2 * i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
-                const u32 hi = (2 * i + 1 <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
+                const u32 lo = (i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
+                const u32 hi = (NP + i <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
                 C[i] = lo | (hi << 16);
             }
         }
@@ -1276,7 +1322,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         const int eoff = want ? xb_in_off + par_in * (2 * 8 * V3_XW * 4) : zero_off;
         v3_edges_issue(xrsrc, eoff, er);
         // ---- straight path: needs nobody else's state
-        sgm_update<NP, true, 8, true, true>(L0, C, C, C, P1pk, P2a, mn0, inact, first, last);
+        sgm_update_split<NP, 8>(L0, C, P1pk, P2a, mn0, first, last);
         v3_edges_complete(xrsrc, eoff, want, Tin, er, dead);
         {
             const u32 e[13] = {er.a.x, er.a.y, er.a.z, er.a.w, er.b.x, er.b.y, er.b.z, er.b.w,
@@ -1298,14 +1344,14 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
         __builtin_nontemporal_store(pend_b, (u32x2 *)(sv_f + pend_ob));
         // ---- NW / SW, then NE / SE; each publishes its edge pixel as soon as it is known
-        sgm_update<NP, true, 8, true, true>(L1, C, C, C, P1pk, P2b, mn1, inact, first, last);
+        sgm_update_split<NP, 8>(L1, C, P1pk, P2b, mn1, first, last);
         if (t + 1 < Hp && g == 7 && has_right) { // the last pixel's state goes to the right wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (0 * 8 + lg) * V3_XW;
 #pragma unroll
             for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], L1[i + 3]};
             q[NP] = mn1 | Tout;
         }
-        sgm_update<NP, true, 8, true, true>(L2, C, C, C, P1pk, P2c, mn2, inact, first, last);
+        sgm_update_split<NP, 8>(L2, C, P1pk, P2c, mn2, first, last);
         if (t + 1 < Hp && g == 0 && has_left) { // the first pixel's state goes to the left wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (1 * 8 + lg) * V3_XW;
 #pragma unroll
@@ -1323,10 +1369,16 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         }
         // ---- one byte per cell: the three paths summed, transposed through LDS into whole-line pieces (store_step)
         {
-            u32 bw[NP / 2];
+            // bytes in disparity order: the low halves of the 12 pairs, then the high halves
+            u32 tq[NP / 2], bw[NP / 2];
 #pragma unroll
-            for (int i = 0; i + 1 < NP; i += 2)
-                bw[i / 2] = __builtin_amdgcn_perm(L0[i + 1] + L1[i + 1] + L2[i + 1], L0[i] + L1[i] + L2[i], 0x06040200u);
+            for (int k = 0; k < NP / 2; k++) // {lo(2k), lo(2k+1), hi(2k), hi(2k+1)} as bytes
+                tq[k] = __builtin_amdgcn_perm(L0[2 * k + 1] + L1[2 * k + 1] + L2[2 * k + 1], L0[2 * k] + L1[2 * k] + L2[2 * k], 0x06020400u);
+#pragma unroll
+            for (int j = 0; j < NP / 4; j++) {
+                bw[j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x05040100u);
+                bw[NP / 4 + j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x07060302u);
+            }
             u32x2 *wp = (u32x2 *)(tr + lane * 6);
             wp[0] = u32x2{bw[0], bw[1]};
             wp[1] = u32x2{bw[2], bw[3]};

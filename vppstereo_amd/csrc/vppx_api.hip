@@ -879,7 +879,10 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
         if (!ctx->sub[i]) {
             if ((rc = vppx_create(&ctx->sub[i], ctx->device))) return rc;
             ctx->sub[i]->is_child = true;
-            ctx->sub[i]->use_vert = ctx->use_vert;
+            // the fused vertical kernel needs all blocks of a (frame, pass) group resident together; two such launches
+            // racing for the same slots on concurrent streams can starve each other (bounded polls would notice, but
+            // why try): sub-stream parts stay on the line-parallel kernel
+            ctx->sub[i]->use_vert = (ctx->use_vert == 1) ? 1 : 0;
             VPPX_HIP(hipEventCreateWithFlags(&ctx->sub_done[i], hipEventDisableTiming));
         }
     }
