@@ -99,6 +99,9 @@ def spawn_ranks(n, argv):
             import torch
             if torch.cuda.device_count() < n:
                 extra = ["--backend", "gloo"]  # ranks must share a device: RCCL refuses duplicate GPUs
+                # ... and the fused vertical kernel wants a GPU's block slots to itself: ranks that
+                # share a device (dry runs only) use the 8-path layout
+                os.environ.setdefault("VPPX_VERT", "0")
         except Exception:
             pass
     port = _free_port()
