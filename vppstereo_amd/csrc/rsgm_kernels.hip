@@ -1399,6 +1399,31 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The lock-step hand-off goes through ONE L2: all blocks of a (frame, pass) group must run on the same XCD, which the
+// kernel gets from "consecutive block ids go round-robin over the XCDs" (group blocks are 8 ids apart).  Checked once
+// per context on the device it runs on: 256 blocks report the XCD they run on (also true, trivially, when the device is
+// a single-XCD partition).
+__global__ void __launch_bounds__(64) xcc_probe_kernel(u32 *out)
+{
+    if (threadIdx.x == 0) {
+        u32 xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        out[blockIdx.x] = xcc & 0xFu;
+    }
+}
+int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *ok)
+{
+    u32 h[256];
+    xcc_probe_kernel<<<256, 64, 0, ctx->stream>>>(scratch_dev);
+    VPPX_CHECK_LAUNCH();
+    VPPX_HIP(hipMemcpyAsync(h, scratch_dev, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    *ok = true;
+    for (int i = 8; i < 256; i++)
+        if (h[i] != h[i & 7]) *ok = false;
+    return 0;
+}
+
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
 {
     // edge values and their packed minimum must stay below 1024 (tag bits), the three-path sum below 256

@@ -409,7 +409,18 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     // (round-1 experiment), 3 = fused vertical kernel whenever the shape allows it.  The fused kernel wins from 8 frames
     // per launch on (540x960x192, ms per step 8-path / fused: B=4 2.24 / 2.38, B=8 3.76 / 3.69, B=16 7.03 / 6.23,
     // B=32 13.3 / 12.3); a context whose fused launch once lost its lock step never uses it again.
-    const bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
+    bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
+    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
+        // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes?
+        u32 *probe;
+        bool ok = false;
+        if ((rc = ws_get(ctx, WS_VMIN, (size_t)512, (u16 **)&probe))) return rc;
+        if ((rc = rsgm_vert3_probe(ctx, probe, &ok))) return rc;
+        ctx->vert3_probed = true;
+        if (!ok) ctx->vert3_broken = true;
+        v3_ok = ok;
+    }
+    if (ctx->capturing && !ctx->vert3_probed) v3_ok = false; // (a first call inside a graph capture takes the 8-path layout)
     const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8));
     const bool vert = vert3 || (ctx->use_vert == 1 && elem_bytes == 1 && rsgm_vert_supported(g.D, maxp2) && g.D <= 192);
     ctx->last_vert = vert3 ? 3 : (vert ? 1 : 0);
@@ -829,6 +840,13 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
         key.ws_gen = ctx->ws_gen;
         // the graph does not contain the penalty-table upload: it must still be the table of these parameters
         const bool lut_ok = ctx->lut_valid && ctx->lut_p2min == rp->p2min && ctx->lut_gamma == rp->gamma && ctx->lut_alpha == rp->alpha;
+        if (ctx->vert3_err && ctx->vert3_err[0] && ctx->gexec) {
+            // the captured graph holds the fused launch that just lost its lock step: drop it (the eager call below
+            // reports the failure once and moves the context to the 8-path layout)
+            (void)hipGraphExecDestroy(ctx->gexec);
+            ctx->gexec = nullptr;
+            ctx->have_gkey = false;
+        }
         if (lut_ok && ctx->gexec && ctx->have_gkey && memcmp(&key, &ctx->gkey, sizeof(key)) == 0) {
             VPPX_HIP(hipGraphLaunch(ctx->gexec, ctx->stream));
             ctx->graph_replays++;

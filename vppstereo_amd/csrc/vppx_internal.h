@@ -115,7 +115,8 @@ struct vppx_ctx {
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
     int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
     unsigned *vert3_err = nullptr; // pinned host word the fused vertical kernel sets when a wave gave up waiting
-    bool vert3_broken = false;     // set once vert3_err was seen: the context stays on the line-parallel kernel
+    bool vert3_broken = false;     // set once vert3_err was seen (or the XCD probe failed): the context stays on the line-parallel kernel
+    bool vert3_probed = false;     // rsgm_vert3_probe has run on this context's device
     DevBuf ws[WS_NUM];
     std::string devname;
     // libc-like stream state of the single-frame scans
@@ -212,6 +213,7 @@ int rsgm_launch_guided_dsi(vppx_ctx *ctx, const RsgmGeom &g, u16 *dsi, const flo
 int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr,
                       const u16 *dsi, const u16 *p2lut, int p1, void *paths, int elem_bytes, int dir_mask);
 // band-marching vertical/diagonal paths (3 summed paths per pass, one byte per cell)
+int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev, bool *ok);
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
