@@ -1236,6 +1236,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
 {
     constexpr int DPL = 24, NP = 12, D = 192;
     __shared__ __attribute__((aligned(16))) u32 s_lut[256 + 4 * TR_WORDS];
+    __shared__ u32 s_mask[NP * 256]; // [pair][thread]: validity masks of the lanes whose column is below D - 1
     s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
     __syncthreads();
     const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
@@ -1266,7 +1267,15 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     const int zero_off = (int)((size_t)2 * a.B * a.nwv * REC) * 4; // one record nobody writes
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, zero_off + V3_XW * 4, 0x00020000);
     const int bp_left = ((lane - 8) & 63) << 2, bp_right = ((lane + 8) & 63) << 2;
-    const bool masked = wv * 8 < D - 1; // some d > x in this wave: InvalidDispCost
+    // Some d > x in this wave (the leftmost 24 waves of a pass): those cells cost InvalidDispCost.  A lane's column never
+    // changes, so which halves of its pairs are valid is a per-lane constant: 12 mask words per lane, kept in LDS (the
+    // lock step makes the whole group run at the pace of these waves: their extra work per row counts 120-fold).
+    const bool masked = wv * 8 < D - 1;
+    if (masked) {
+        const int lim = x - dbase;
+#pragma unroll
+        for (int i = 0; i < NP; i++) s_mask[i * 256 + threadIdx.x] = (i <= lim ? 0xFFFFu : 0u) | (NP + i <= lim ? 0xFFFF0000u : 0u);
+    }
     u32 inact[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) inact[i] = 0;
@@ -1298,13 +1307,12 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
             const u32 c1 = __popc(A.clv ^ A.w[DPL - 1 - NP - i]);
             C[i] = (c1 << 16) | c0;
         }
-        if (masked) {
-            const int lim = x - dbase;
+        if (masked) { // one bit-field insert per pair: keep the halves with d <= x, InvalidDispCost in the others
+            constexpr u32 INVpk = INVALID_DISP_COST | (INVALID_DISP_COST << 16);
 #pragma unroll
             for (int i = 0; i < NP; i++) {
-                const u32 lo = (i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
-                const u32 hi = (NP + i <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
-                C[i] = lo | (hi << 16);
+                const u32 m = s_mask[i * 256 + threadIdx.x];
+                C[i] = (m & C[i]) | (~m & INVpk);
             }
         }
         const int I = A.I;
