@@ -1,0 +1,84 @@
+"""GPU: the fused aggregation layout (W/E line-parallel + sgm_vert3_kernel) against the 8-path layout
+on random shapes, batch sizes and penalty parameters.  The two layouts share no aggregation code for the six vertical
+and diagonal paths (register-resident lock-step kernel with neighbour hand-off vs one independent chain per scan line),
+so equality of every disparity is a strong check; a few frames are also compared with the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines():
+    import os
+    import torch
+    from vppstereo_amd.engine import Engine
+    assert torch.cuda.is_available()
+    old = os.environ.get("VPPX_VERT")
+    try:
+        os.environ["VPPX_VERT"] = "3"   # fused whenever the shape allows it
+        fused = Engine()
+        os.environ["VPPX_VERT"] = "0"   # always the eight line-parallel paths
+        eight = Engine()
+    finally:
+        if old is None:
+            os.environ.pop("VPPX_VERT", None)
+        else:
+            os.environ["VPPX_VERT"] = old
+    return fused, eight
+
+
+def _case(rng):
+    B = int(rng.choice([4, 8, 12, 16]))
+    H = int(rng.integers(5, 70))
+    W = int(rng.integers(5, 330))
+    p2min = int(rng.integers(5, 40))
+    kw = dict(dmax=192, p1=int(rng.integers(1, 25)), p2min=p2min, gamma=int(rng.integers(p2min, 62)),
+              alpha=float(rng.choice([0.0, 0.25, 0.5, 1.0])), subpixel=int(rng.integers(0, 2)),
+              uniqueness=float(rng.choice([0.95, 0.8, 1.0])))
+    return B, H, W, kw
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_fused_layout_equals_eight_path_layout(engines, seed):
+    import torch
+    fused, eight = engines
+    rng = np.random.default_rng(1000 + seed)
+    B, H, W, kw = _case(rng)
+    if seed == 0:
+        B, H, W = 8, 5, 5            # the smallest frame the library takes: pads to 16 x 16, two 8-column waves, both at a border
+    if seed == 1:
+        kw.update(p2min=61, gamma=61, alpha=0.0)   # 3 * (24 + 61) = 255: the largest sums a byte volume can hold
+    b = synth.make_batch(B, H, W, 192, float(rng.choice([0.0, 0.03, 0.3])), seed=seed)
+    dev = fused.device
+    args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints")]
+    out_f = fused.vpp_rsgm(*args, seed=seed, rsgm_kw=kw)
+    out_8 = eight.vpp_rsgm(*args, seed=seed, rsgm_kw=kw)
+    torch.cuda.synchronize()
+    assert fused.uses_vert() == 3 and eight.uses_vert() == 0, (B, H, W, kw)
+    assert torch.equal(out_f, out_8), (B, H, W, kw, int((out_f != out_8).sum()))
+    if seed % 5 == 0:   # and against the oracle (frame 0 and the last one)
+        got = out_f.cpu().numpy()
+        for f in (0, B - 1):
+            oracle.init_rand(seed + f)
+            lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
+            okw = dict(kw)
+            okw["subpixel"] = bool(okw["subpixel"])
+            assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, **okw), got[f]), (f, B, H, W, kw)
+
+
+def test_fused_layout_wants_byte_sized_three_path_sums(engines):
+    """3 * (24 + P2max) > 255: the three-path sum does not fit a byte, the library must stay on the 8-path layout."""
+    import torch
+    fused, _ = engines
+    b = synth.make_batch(8, 20, 40, 192, 0.05, seed=3)
+    args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(fused.device) for k in ("left", "right", "hints")]
+    out = fused.vpp_rsgm(*args, seed=1, rsgm_kw=dict(dmax=192, p2min=17, gamma=62, alpha=0.5))
+    torch.cuda.synchronize()
+    assert fused.uses_vert() == 0
+    oracle.init_rand(1)
+    lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
+    assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, dmax=192, p2min=17, gamma=62, alpha=0.5), out[0].cpu().numpy())
