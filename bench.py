@@ -60,6 +60,9 @@ def parse(argv=None):
                                                     "ranks have to share a GPU: dry runs)")
     ap.add_argument("--shape", type=float, nargs=4, metavar=("H", "W", "D", "P"), default=None,
                     help="other BASELINE configs, e.g. --shape 375 1242 192 0.05 (KITTI) or 1536 2048 256 0.01")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap the front stage of step k+1 (occlusion heuristic, VPP, pad, census) with the "
+                         "sum / WTA and post kernels of step k (Engine.set_pipeline)")
     ap.add_argument("--graph", action="store_true",
                     help="run on a side stream with hipGraph replay of the fused call (small batches are launch-bound)")
     ap.add_argument("--uniform-random", action="store_true",
@@ -286,6 +289,9 @@ def run_rank(args):
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
     eng = Engine(dev_index)
+    # consecutive steps are independent batches whose inputs are resident: the front stage of the next step may run on
+    # a second stream under the tail of this one (ignored under --graph, where a step is one captured graph)
+    eng.set_pipeline(not args.no_pipeline)
     if args.graph:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # stream capture needs a non-default stream
         eng.set_graph_mode(True)
@@ -446,7 +452,10 @@ def run_rank(args):
             "data": "synthetic (uniform random u8)" if args.uniform_random else "synthetic",
             "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, {occ_txt}VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
                                    f"{B} frames/GPU/step resident in HBM", "frames_per_step": n_total,
-                       "H": H, "W": W, "D": D, "hint_density": P_HINTS, "g_occ": "occlusion_heuristic" if use_occ else None},
+                       "H": H, "W": W, "D": D, "hint_density": P_HINTS, "g_occ": "occlusion_heuristic" if use_occ else None,
+                       "cross_step_overlap": (None if (args.no_pipeline or args.graph) else
+                                              "front stage of step k+1 (occlusion heuristic, VPP, pad+gray, census) on a second "
+                                              "stream under the sum/WTA and post kernels of step k")},
             "ranks": {"launched": args.gpus, "seen": dist.get_world_size() if world > 1 else 1,
                       "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
                       "ms_per_step_per_rank": [round(x, 3) for x in rank_ms]},
@@ -471,7 +480,8 @@ def run_rank(args):
                                   "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4)},
             ("ms_per_step_without_g_occ" if use_occ else "ms_per_step_with_g_occ"): other,
             "b1": {"ms_per_frame": round(b1_ms, 4), "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),
-                   "what": "one frame per call (B=1), host-paced loop of 20 calls, same stages as the step"},
+                   "what": "one frame per call (B=1), host-paced loop of 20 calls, same stages as the step"
+                           + ("" if (args.no_pipeline or args.graph) else "; consecutive calls overlap like the steps (cross_step_overlap)")},
             "stage_ms": {k: round(v, 3) for k, v in stages.items()},
             "kernel_source_sha": kernel_source_sha(),
             "device": eng.ctx.device_name,

@@ -121,6 +121,15 @@ int vppx_set_stream(vppx_ctx *ctx, void *hip_stream);
 /* Launch on the legacy default ("null") stream itself -- what torch's default stream is (its handle is 0, which
  * vppx_set_stream reads as "own stream").  All work is then ordered with the caller's default-stream work. */
 int vppx_set_stream_legacy(vppx_ctx *ctx);
+
+/* Cross-call pipelining for streams of batches through vppx_occlusion_heuristic_dev + vppx_vpp_rsgm_dev: with `on`, the
+ * front stage of a call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the
+ * PREVIOUS call's aggregation is done, i.e. next to that call's sum / WTA and post kernels.  Outputs keep the launch
+ * stream's order (it waits for the front stage).  Inputs must be ready when the call is made: work queued on the launch
+ * stream after the previous call is NOT waited for by the front stage; likewise the buffers the front stage writes
+ * (conf_out, l_vpp, r_vpp) must not be memory that earlier queued work still has to read.  Off by default; ignored during graph capture,
+ * stage timing and for sub-stream parts.  (No reference counterpart: test.py handles one pair at a time.) */
+int vppx_set_pipeline(vppx_ctx *ctx, int on);
 int vppx_synchronize(vppx_ctx *ctx);
 /* Bytes of device workspace currently held by the context. */
 size_t vppx_workspace_bytes(const vppx_ctx *ctx);

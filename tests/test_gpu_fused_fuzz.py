@@ -82,3 +82,39 @@ def test_fused_layout_wants_byte_sized_three_path_sums(engines):
     oracle.init_rand(1)
     lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
     assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, dmax=192, p2min=17, gamma=62, alpha=0.5), out[0].cpu().numpy())
+
+
+def test_cross_call_pipelining_keeps_results_and_stream_order():
+    """Engine.set_pipeline: the front stage of call k+1 runs on a second stream under call k's sum / post kernels.  A
+    stream of different batches (with the occlusion mask) must give the unpipelined results, and torch work queued on
+    the current stream right after a call must see that call's finished disparities.  The buffers the front stage
+    writes (the occlusion mask) are persistent, as the mode requires: a tensor allocated per call could reuse memory
+    that work still queued on the main stream has not read yet (torch's allocator only knows the main stream)."""
+    import torch
+    from vppstereo_amd.engine import Engine
+    ref_eng, eng = Engine(), Engine()
+    eng.set_pipeline(True)
+    dev = eng.device
+    shapes = [(8, 40, 120), (8, 40, 120), (12, 33, 70), (4, 25, 50), (8, 40, 120)]
+    batches, occ_bufs, out_bufs = [], [], []
+    for i, (B, H, W) in enumerate(shapes):
+        b = synth.make_batch(B, H, W, 192, 0.05, seed=50 + i)
+        batches.append([torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints")])
+        occ_bufs.append(torch.empty((B, H, W), dtype=torch.uint8, device=dev))
+        out_bufs.append([torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(3)])
+    refs = []
+    for i, (l, r, h) in enumerate(batches):
+        occ = ref_eng.occlusion_heuristic(h)
+        refs.append(ref_eng.vpp_rsgm(l, r, h, g_occ=occ, seed=i, rsgm_kw=dict(dmax=192)).clone())
+    torch.cuda.synchronize()
+    sums = []
+    for rep in range(3):          # no synchronisation inside: calls, and torch reductions right behind them, pile up
+        for i, (l, r, h) in enumerate(batches):
+            occ = eng.occlusion_heuristic(h, out=occ_bufs[i])
+            out = eng.vpp_rsgm(l, r, h, g_occ=occ, out=out_bufs[i][rep], seed=i, rsgm_kw=dict(dmax=192))
+            sums.append(out.double().sum())       # torch kernel on the same stream, queued immediately
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i in range(len(batches)):
+            assert torch.equal(out_bufs[i][rep], refs[i]), (rep, i)
+            assert float(sums[rep * len(batches) + i]) == float(refs[i].double().sum()), (rep, i)

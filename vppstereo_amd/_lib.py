@@ -23,7 +23,7 @@ ERR_NAMES = {
 # every symbol include/vppx.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "vppx_version", "vppx_last_error", "vppx_vpp_params_default", "vppx_rsgm_params_default", "vppx_create",
-    "vppx_destroy", "vppx_set_stream", "vppx_set_stream_legacy", "vppx_synchronize", "vppx_workspace_bytes", "vppx_device_name", "vppx_srand",
+    "vppx_destroy", "vppx_set_stream", "vppx_set_stream_legacy", "vppx_set_pipeline", "vppx_synchronize", "vppx_workspace_bytes", "vppx_device_name", "vppx_srand",
     "vppx_rand_stream", "vppx_rand_state", "vppx_rand_advance", "vppx_virtual_projection_scan_rnd", "vppx_virtual_projection_scan_max_dist", "vppx_vpp_host",
     "vppx_vpp_dev", "vppx_vpp_last_draws", "vppx_census5x5", "vppx_cost_census5x5_xyd", "vppx_aggregate", "vppx_aggregate_img", "vppx_match_wta",
     "vppx_match_wta_right", "vppx_subpixel_refine", "vppx_median3x3", "vppx_rsgm_host", "vppx_rsgm_dev",
@@ -95,6 +95,7 @@ def load():
         lib.vppx_destroy.restype = None
         lib.vppx_set_stream.argtypes = [vp, vp]
         lib.vppx_set_stream_legacy.argtypes = [vp]
+        lib.vppx_set_pipeline.argtypes = [vp, C.c_int]
         lib.vppx_synchronize.argtypes = [vp]
         lib.vppx_srand.argtypes = [vp, C.c_uint32]
         lib.vppx_rand_state.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]

@@ -1766,7 +1766,7 @@ int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, i
     const size_t n = (size_t)B * H * W;
     dim3 grid((W + 255) / 256, H, B);
     int *tmp = nullptr;
-    int rc = ws_get(ctx, WS_LABEL, n, &tmp);
+    int rc = ws_get(ctx, WS_OCC_TMP, n, &tmp);
     if (rc) return rc;
     VPPX_HIP(hipMemsetAsync(omap, 0, n * sizeof(float), ctx->stream));
     occ_warp_kernel<<<grid, 256, 0, ctx->stream>>>(hints, (int *)omap, H, W);

@@ -179,6 +179,9 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
             for (int i = 0; i < vppx_ctx::AGG_RING; i++) (void)hipEventDestroy(ctx->agg_ev[j][i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->vert3_err) (void)hipHostFree(ctx->vert3_err);
+    if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
+    if (ctx->ev_agg_done) (void)hipEventDestroy(ctx->ev_agg_done);
+    if (ctx->ev_front_done) (void)hipEventDestroy(ctx->ev_front_done);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -505,6 +508,55 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
 // ---------------------------------------------------------------------------------------
 // rSGM on device buffers (core of compute_rsgm, rsgm.py:250-294)
 // ---------------------------------------------------------------------------------------
+// ---- cross-call pipelining of the front stage (vppx_set_pipeline) ----
+static bool pipeline_applies(const vppx_ctx *ctx)
+{
+    return ctx->pipeline && !ctx->capturing && !ctx->stage_timing && !ctx->is_child && !ctx->graph_mode && ctx->nsub <= 1;
+}
+// From here on ctx->stream is the front stream.  It waits for the previous pipelined call's aggregation (the last
+// reader of the census / gray / pattern buffers the front stage rewrites); the first pipelined call waits for
+// everything queued on the launch stream so far.
+static int front_begin(vppx_ctx *ctx)
+{
+    if (!ctx->stream_front) {
+        VPPX_HIP(hipStreamCreateWithFlags(&ctx->stream_front, hipStreamNonBlocking));
+        VPPX_HIP(hipEventCreateWithFlags(&ctx->ev_agg_done, hipEventDisableTiming));
+        VPPX_HIP(hipEventCreateWithFlags(&ctx->ev_front_done, hipEventDisableTiming));
+    }
+    if (!ctx->have_agg_done) {
+        VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
+        ctx->have_agg_done = true;
+    }
+    VPPX_HIP(hipStreamWaitEvent(ctx->stream_front, ctx->ev_agg_done, 0));
+    ctx->main_saved = ctx->stream;
+    ctx->stream = ctx->stream_front;
+    ctx->front_active = true;
+    return 0;
+}
+// Back to the launch stream, which from now on waits for the front stage: whatever is queued on it later (this call's
+// aggregation, the caller's own work) sees the front stage's results.
+static int front_end(vppx_ctx *ctx)
+{
+    if (!ctx->front_active) return 0;
+    hipStream_t front = ctx->stream;
+    ctx->stream = ctx->main_saved;
+    ctx->front_active = false;
+    VPPX_HIP(hipEventRecord(ctx->ev_front_done, front));
+    VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_front_done, 0));
+    return 0;
+}
+struct FrontGuard { // error paths: never leave the context on the front stream
+    vppx_ctx *ctx;
+    ~FrontGuard()
+    {
+        if (ctx->front_active) {
+            ctx->stream = ctx->main_saved;
+            ctx->front_active = false;
+        }
+        ctx->pipe_call = false;
+    }
+};
+
 static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, const u8 *left, const u8 *left_vpp,
                      const u8 *right_vpp, float *disp_out, const float *hints = nullptr, const float *validhints = nullptr)
 {
@@ -529,6 +581,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
         if ((rc = rsgm_launch_census_n(ctx, g.B, g.Hp, g.Wp, 2, gsrc, cdst))) return rc;
         stage_mark(ctx, ST_CENSUS);
     }
+    if ((rc = front_end(ctx))) return rc; // pipelined call: the front stage ends here
 
     u16 *lut_d;
     if ((rc = ws_get(ctx, WS_P2LUT, 256, &lut_d))) return rc;
@@ -544,6 +597,10 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const void *vols[8];
     int nvol = 0, elem_bytes = 1;
     if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0, hints, validhints))) return rc;
+    if (ctx->pipe_call) { // the next pipelined call's front stage may start now
+        VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
+        ctx->have_agg_done = true;
+    }
     stage_mark(ctx, ST_AGGREGATE);
     ctx->last_B = g.B; ctx->last_Hp = g.Hp; ctx->last_Wp = g.Wp; ctx->last_D = g.D; ctx->last_rp = p; ctx->have_last = true;
 
@@ -800,6 +857,11 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmPa
     const size_t nb = (size_t)B * H * W * C;
     if (!l_vpp && (rc = ws_get(ctx, WS_VPP_L, nb, &l_vpp))) return rc;
     if (!r_vpp && (rc = ws_get(ctx, WS_VPP_R, nb, &r_vpp))) return rc;
+    FrontGuard guard{ctx};
+    if (pipeline_applies(ctx)) {
+        ctx->pipe_call = true;
+        if ((rc = front_begin(ctx))) return rc;
+    }
     stage_begin(ctx);
     // vpp() works on copies (np.copy, vpp_standalone.py:397)
     VPPX_HIP(hipMemcpyAsync(l_vpp, left, nb, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1025,7 +1087,25 @@ extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, 
     u8 *conf;
     if ((rc = ws_get(ctx, WS_OCC_OMAP, n, &omap))) return rc;
     if ((rc = ws_get(ctx, WS_OCC_CONF, n, &conf))) return rc;
-    return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out);
+    FrontGuard guard{ctx};
+    if (pipeline_applies(ctx) && (rc = front_begin(ctx))) return rc; // part of the next fused call's front stage
+    if ((rc = occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out))) return rc;
+    return front_end(ctx);
+}
+
+// Cross-call pipelining for streams of batches through occlusion_heuristic + vpp_rsgm (bench.py, serving loops): the
+// front stage of a call runs on a second stream as soon as the previous call's aggregation is done, next to that call's
+// sum / WTA and post kernels.  Results keep the launch stream's order (it waits for the front stage); INPUTS must be
+// ready when the call is made: a tensor produced by work queued on the launch stream after the previous call is not
+// waited for.  Off by default.
+extern "C" int vppx_set_pipeline(vppx_ctx *ctx, int on)
+{
+    int rc;
+    VPPX_ENTER(ctx);
+    (void)rc;
+    ctx->pipeline = on != 0;
+    ctx->have_agg_done = false;
+    return 0;
 }
 
 extern "C" int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,

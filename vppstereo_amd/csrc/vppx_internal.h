@@ -86,6 +86,7 @@ enum WsSlot {
     WS_STAGE_F,
     WS_OCC_OMAP,
     WS_OCC_CONF,
+    WS_OCC_TMP,       // unwarp scratch of the occlusion heuristic (its own slot: with vppx_set_pipeline it runs next to the previous call's speckle filter, which owns WS_LABEL)
     WS_NHINTS,
     WS_HANDOFF_H,    // hints / valid at feature resolution (hand-off kernels)
     WS_HANDOFF_V,
@@ -114,6 +115,14 @@ struct vppx_ctx {
     bool is_child = false;
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
     int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
+    // cross-call pipelining (vppx_set_pipeline): the front stage of a fused call (occlusion heuristic, VPP, pad + gray,
+    // census) runs on stream_front, after the PREVIOUS call's aggregation, i.e. under that call's sum / WTA and post kernels
+    bool pipeline = false;
+    bool front_active = false;     // ctx->stream currently is stream_front
+    bool pipe_call = false;        // the running vpp_rsgm call is pipelined (record ev_agg_done after its aggregation)
+    bool have_agg_done = false;
+    hipStream_t stream_front = nullptr, main_saved = nullptr;
+    hipEvent_t ev_agg_done = nullptr, ev_front_done = nullptr;
     unsigned *vert3_err = nullptr; // pinned host word the fused vertical kernel sets when a wave gave up waiting
     bool vert3_broken = false;     // set once vert3_err was seen (or the XCD probe failed): the context stays on the line-parallel kernel
     bool vert3_probed = false;     // rsgm_vert3_probe has run on this context's device

@@ -235,6 +235,16 @@ class Engine:
                                                 int(bool(little_endian)), _ptr(out)))
         return out
 
+    def set_pipeline(self, enable=True):
+        """Cross-call pipelining for streams of batches through `occlusion_heuristic` + `vpp_rsgm`: the front stage of a
+        call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the previous call's
+        aggregation is done, next to that call's sum / WTA and post kernels.  Outputs keep torch's stream order; INPUTS
+        must be ready when the call is made (tensors produced by work queued on the current stream after the previous call
+        are not waited for), and the buffers the front stage writes (`occlusion_heuristic(out=)`, `l_vpp`, `r_vpp`) must be
+        persistent: a tensor allocated per call may reuse memory that work still queued on the current stream has not
+        read yet (torch's caching allocator orders reuse on the current stream only).  Off by default."""
+        _lib.check(self.lib.vppx_set_pipeline(self.ctx.handle, int(bool(enable))))
+
     def set_graph_mode(self, enable=True):
         """hipGraph replay of repeated identical vpp_rsgm calls (same tensors, parameters and stream; needs a
         non-default torch stream).  `graph_replays()` counts the calls served by a graph launch."""
