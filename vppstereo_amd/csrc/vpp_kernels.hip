@@ -266,7 +266,7 @@ __device__ __forceinline__ void srand_basis(u32 seed, u32 (&v)[31])
     for (int i = 0; i < 31; i++) v[i] = (u32)r[(i + 3) % 31];
 }
 
-__global__ void __launch_bounds__(64) rand_kernel(u8 *__restrict__ out, size_t cap, const unsigned long long *__restrict__ frame_tot,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) rand_kernel(u8 *__restrict__ out, size_t cap, const unsigned long long *__restrict__ frame_tot,
                                                   const u32 *__restrict__ seeds, u32 seed0, Poly31 qoff,
                                                   const u32 *__restrict__ tab /*[nblk][31]*/, int nblk)
 {
