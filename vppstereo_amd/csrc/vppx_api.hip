@@ -410,8 +410,8 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
     // Aggregation layout.  use_vert: -1 (default) = pick by shape, 0 = eight line-parallel paths, 1 = band marching
     // (round-1 experiment), 3 = fused vertical kernel whenever the shape allows it.  The fused kernel wins from 8 frames
-    // per launch on (540x960x192, ms per step 8-path / fused: B=4 2.24 / 2.38, B=8 3.76 / 3.69, B=16 7.03 / 6.23,
-    // B=32 13.3 / 12.3); a context whose fused launch once lost its lock step never uses it again.
+    // per launch on (540x960x192, ms per step 8-path / fused: B=4 2.20 / 2.26, B=8 3.74 / 3.27, B=16 6.94 / 5.90,
+    // B=32 13.3 / 11.7); a context whose fused launch once lost its lock step never uses it again.
     bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
     if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
         // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes?
