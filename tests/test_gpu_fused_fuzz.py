@@ -36,13 +36,13 @@ def _case(rng):
     H = int(rng.integers(5, 70))
     W = int(rng.integers(5, 330))
     p2min = int(rng.integers(5, 40))
-    kw = dict(dmax=192, p1=int(rng.integers(1, 25)), p2min=p2min, gamma=int(rng.integers(p2min, 62)),
+    kw = dict(dmax=int(rng.choice([64, 128, 192, 192, 256])), p1=int(rng.integers(1, 25)), p2min=p2min, gamma=int(rng.integers(p2min, 62)),
               alpha=float(rng.choice([0.0, 0.25, 0.5, 1.0])), subpixel=int(rng.integers(0, 2)),
               uniqueness=float(rng.choice([0.95, 0.8, 1.0])))
     return B, H, W, kw
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", range(24))
 def test_fused_layout_equals_eight_path_layout(engines, seed):
     import torch
     fused, eight = engines
@@ -52,7 +52,7 @@ def test_fused_layout_equals_eight_path_layout(engines, seed):
         B, H, W = 8, 5, 5            # the smallest frame the library takes: pads to 16 x 16, two 8-column waves, both at a border
     if seed == 1:
         kw.update(p2min=61, gamma=61, alpha=0.0)   # 3 * (24 + 61) = 255: the largest sums a byte volume can hold
-    b = synth.make_batch(B, H, W, 192, float(rng.choice([0.0, 0.03, 0.3])), seed=seed)
+    b = synth.make_batch(B, H, W, kw["dmax"], float(rng.choice([0.0, 0.03, 0.3])), seed=seed)
     dev = fused.device
     args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints")]
     out_f = fused.vpp_rsgm(*args, seed=seed, rsgm_kw=kw)

@@ -1111,7 +1111,7 @@ int rsgm_launch_vert(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, i
 }
 
 // ---------------------------------------------------------------------------------------
-// Vertical / diagonal paths three at a time with the state in registers (round 2; D = 192 byte variant).
+// Vertical / diagonal paths three at a time with the state in registers (round 2; byte volumes, D = 8 * DPL).
 // One launch runs two passes per frame: pass 0 walks the rows top-down and carries N, NW, NE; pass 1 walks
 // bottom-up and carries S, SW, SE.  A wave owns 8 neighbouring columns (8 lanes x 24 disparities per pixel, the
 // layout of sgm_paths_kernel<8, 24>) for the whole pass and keeps the three paths' L_r of the previous row in
@@ -1179,13 +1179,12 @@ struct Vert3Args {
     const u32 *cr;
     const u16 *p2lut;
     u8 *sv;     // [2 passes][B][Hp][Wp][D]
-    u32 *xbuf;  // [2B groups][nwv][V3_RING rows][2 directions][8 lanes][V3_XW] edge records
+    u32 *xbuf;  // [2B groups][nwv][V3_RING rows][2 directions][8 lanes][XW] edge records
     unsigned *err; // host-visible word, set when a wave gave up waiting for a neighbour (results void)
     int B, Hp, Wp, p1;
     int nwv, nbg; // waves / blocks per group
     size_t vol_elems;
 };
-#define V3_XW 16 // dwords per lane of an edge record: 12 pairs, the packed minimum, 3 pad
 #define V3_SPIN_LIMIT (1 << 16)
 // Rows of edge records kept per wave.  A wave may write the record of row t+1 while a neighbour is still reading the
 // one of row t-1 (the NW record of a row is published before the NE record of the row before has been consumed), so
@@ -1200,42 +1199,52 @@ struct Vert3Args {
 // runs, v3_edges_complete checks the tags, polls again while a record is not there yet, and strips the tags.
 // One tag per 16-byte piece (its first dword; a lane's aligned 16-byte store and 16-byte load are single requests
 // to one cache line, so a piece is seen whole or not at all) and one on the minimum.
+template <int NP>
 struct V3Edge {
-    u32x4 a, b, c;
-    u32 m;
+    u32x4 p[NP / 4]; // the NP pairs in 16-byte pieces
+    u32 m;           // the packed minimum
 };
 #define V3_SC1 16 // cache-policy operand of the buffer load builtins: bit 4 = sc1 on gfx940+
-__device__ __forceinline__ void v3_edges_issue(__amdgpu_buffer_rsrc_t xr, int off, V3Edge &r)
+template <int NP>
+__device__ __forceinline__ void v3_edges_issue(__amdgpu_buffer_rsrc_t xr, int off, V3Edge<NP> &r)
 {
-    r.a = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, V3_SC1);
-    r.b = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, V3_SC1);
-    r.c = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 32, 0, V3_SC1);
-    r.m = __builtin_amdgcn_raw_buffer_load_b32(xr, off + 48, 0, V3_SC1);
+#pragma unroll
+    for (int k = 0; k < NP / 4; k++) r.p[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16 * k, 0, V3_SC1);
+    r.m = __builtin_amdgcn_raw_buffer_load_b32(xr, off + 4 * NP, 0, V3_SC1);
 }
-__device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int off, bool want, u32 T, V3Edge &r, bool &dead)
+template <int NP>
+__device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int off, bool want, u32 T, V3Edge<NP> &r, bool &dead)
 {
     int spins = dead ? V3_SPIN_LIMIT - 2 : 0; // a wave that gave up once does not wait again (results are void anyway)
     for (;;) {
-        const u32 bad = ((r.a.x ^ T) | (r.b.x ^ T) | (r.c.x ^ T) | (r.m ^ T)) & V3_TAGMASK;
-        const bool ok = !want || bad == 0;
+        u32 bad = r.m ^ T;
+#pragma unroll
+        for (int k = 0; k < NP / 4; k++) bad |= r.p[k].x ^ T;
+        const bool ok = !want || (bad & V3_TAGMASK) == 0;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         if (++spins >= V3_SPIN_LIMIT) {
             dead = true;
             break;
         }
         __builtin_amdgcn_s_sleep(1);
-        v3_edges_issue(xr, off, r);
+        v3_edges_issue<NP>(xr, off, r);
     }
-    r.a.x &= ~V3_TAGMASK;
-    r.b.x &= ~V3_TAGMASK;
-    r.c.x &= ~V3_TAGMASK;
+#pragma unroll
+    for (int k = 0; k < NP / 4; k++) r.p[k].x &= ~V3_TAGMASK;
     r.m &= ~V3_TAGMASK;
 }
 
+// dwords per lane of an edge record (NP pairs + the packed minimum, rounded up to whole 64-byte slots)
+template <int NP>
+struct V3Rec { static constexpr int XW = (NP + 1 <= 16) ? 16 : 32; };
+
+template <int DPL>
 __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
 {
-    constexpr int DPL = 24, NP = 12, D = 192;
-    __shared__ __attribute__((aligned(16))) u32 s_lut[256 + 4 * TR_WORDS];
+    constexpr int NP = DPL / 2, D = 8 * DPL, V3_XW = V3Rec<NP>::XW;
+    static_assert(NP % 4 == 0, "edge records are made of 16-byte pieces");
+    constexpr int TRW = (DPL == 24) ? TR_WORDS : (DPL == 32 ? 512 : 1); // store transposition words per wave
+    __shared__ __attribute__((aligned(16))) u32 s_lut[256 + 4 * TRW];
     __shared__ u32 s_mask[NP * 256]; // [pair][thread]: validity masks of the lanes whose column is below D - 1
     s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
     __syncthreads();
@@ -1252,7 +1261,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     const u32 *cl_f = a.cl + fpix;
     const u32 *cr_f = a.cr + fpix;
     u8 *sv_f = a.sv + (size_t)pass * a.vol_elems + fpix * D;
-    u32 *tr = s_lut + 256 + (threadIdx.x >> 6) * TR_WORDS;
+    u32 *tr = s_lut + 256 + (threadIdx.x >> 6) * TRW;
     const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
     const bool first = lg == 0, last = lg == 7;
     const bool has_left = wv > 0, has_right = wv + 1 < a.nwv;
@@ -1293,9 +1302,23 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     int Ipl = 0, Ipr = 0;
     // the row's bytes leave one row late (right after the next row's poll), so that no wait of this wave ever has a
     // young volume store in front of it
-    u32x4 pend_a = {0, 0, 0, 0};
-    u32x2 pend_b = {0, 0};
-    u32 pend_oa = ((u32)(y * Wp + wv * 8) * (u32)D) + (u32)lane * 16u, pend_ob = pend_oa; // harmless first store (rewritten)
+    // (DPL 24 / 32: two pieces per lane out of the LDS transposition; DPL 8 / 16: the lane's own 8 / 16 bytes, which
+    // already tile whole lines)
+    u32x4 pend_a = {0, 0, 0, 0}, pend_b = {0, 0, 0, 0};
+    u32 pend_oa = ((u32)(y * Wp + wv * 8) * (u32)D) + (u32)lane * (DPL < 24 ? DPL : 16), pend_ob = pend_oa; // harmless first store (rewritten)
+    auto store_pend = [&]() {
+        if constexpr (DPL == 8) {
+            __builtin_nontemporal_store(u32x2{pend_a.x, pend_a.y}, (u32x2 *)(sv_f + pend_oa));
+        } else if constexpr (DPL == 16) {
+            __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
+        } else if constexpr (DPL == 24) {
+            __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
+            __builtin_nontemporal_store(u32x2{pend_b.x, pend_b.y}, (u32x2 *)(sv_f + pend_ob));
+        } else {
+            __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
+            __builtin_nontemporal_store(pend_b, (u32x4 *)(sv_f + pend_ob));
+        }
+    };
     for (int t = 0; t < Hp; t++, y += dy) {
         const int pixl = y * Wp + x;
         // ---- costs of this row, once for the three paths
@@ -1325,16 +1348,20 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         const int par_in = (t - 1) & (V3_RING - 1), par_out = t & (V3_RING - 1);
         // ---- the neighbours' edges of the previous row: one round trip to L2, covered by the straight path's update
         // lanes that take no record (and everybody in the first row) keep zeros: the path starts / restarts there
-        V3Edge er;
+        V3Edge<NP> er;
         const bool want = edge_lane && t > 0;
         const int eoff = want ? xb_in_off + par_in * (2 * 8 * V3_XW * 4) : zero_off;
-        v3_edges_issue(xrsrc, eoff, er);
+        v3_edges_issue<NP>(xrsrc, eoff, er);
         // ---- straight path: needs nobody else's state
         sgm_update_split<NP, 8>(L0, C, P1pk, P2a, mn0, first, last);
-        v3_edges_complete(xrsrc, eoff, want, Tin, er, dead);
+        v3_edges_complete<NP>(xrsrc, eoff, want, Tin, er, dead);
         {
-            const u32 e[13] = {er.a.x, er.a.y, er.a.z, er.a.w, er.b.x, er.b.y, er.b.z, er.b.w,
-                               er.c.x, er.c.y, er.c.z, er.c.w, er.m};
+            u32 e[NP + 1];
+#pragma unroll
+            for (int q = 0; q < NP / 4; q++) {
+                e[4 * q] = er.p[q].x; e[4 * q + 1] = er.p[q].y; e[4 * q + 2] = er.p[q].z; e[4 * q + 3] = er.p[q].w;
+            }
+            e[NP] = er.m;
             // the two diagonal states move one pixel sideways: inside the wave by ds_bpermute, at its ends from the records
 #pragma unroll
             for (int i = 0; i < NP; i++) {
@@ -1345,12 +1372,11 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
             }
             const u32 m1 = (u32)__builtin_amdgcn_ds_bpermute(bp_left, (int)mn1);
             const u32 m2 = (u32)__builtin_amdgcn_ds_bpermute(bp_right, (int)mn2);
-            mn1 = (g == 0) ? e[12] : m1;
-            mn2 = (g == 7) ? e[12] : m2;
+            mn1 = (g == 0) ? e[NP] : m1;
+            mn2 = (g == 7) ? e[NP] : m2;
         }
         // ---- last row's bytes (everything older has just been drained: this store has a whole row to complete)
-        __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
-        __builtin_nontemporal_store(pend_b, (u32x2 *)(sv_f + pend_ob));
+        store_pend();
         // ---- NW / SW, then NE / SE; each publishes its edge pixel as soon as it is known
         sgm_update_split<NP, 8>(L1, C, P1pk, P2b, mn1, first, last);
         if (t + 1 < Hp && g == 7 && has_right) { // the last pixel's state goes to the right wave
@@ -1387,23 +1413,40 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
                 bw[j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x05040100u);
                 bw[NP / 4 + j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x07060302u);
             }
-            u32x2 *wp = (u32x2 *)(tr + lane * 6);
-            wp[0] = u32x2{bw[0], bw[1]};
-            wp[1] = u32x2{bw[2], bw[3]};
-            wp[2] = u32x2{bw[4], bw[5]};
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            pend_a = *(const u32x4 *)(tr + lane * 4);
-            pend_b = *(const u32x2 *)(tr + 256 + lane * 2);
-            // the wave's 8 pixels are neighbours in memory: bytes [0, 1024) and [1024, 1536) of its 8 x 192
-            const u32 base = (u32)(y * Wp + wv * 8) * (u32)D;
-            pend_oa = base + (u32)lane * 16u;
-            pend_ob = base + 1024u + (u32)lane * 8u;
+            const u32 base = (u32)(y * Wp + wv * 8) * (u32)D; // the wave's 8 pixels are neighbours in memory
+            if constexpr (DPL == 8) {
+                pend_a = u32x4{bw[0], bw[1], 0, 0};
+                pend_oa = base + (u32)lane * 8u;
+            } else if constexpr (DPL == 16) {
+                pend_a = u32x4{bw[0], bw[1], bw[2], bw[3]};
+                pend_oa = base + (u32)lane * 16u;
+            } else if constexpr (DPL == 24) { // bytes [0, 1024) and [1024, 1536) of the wave's 8 x 192 (store_step)
+                u32x2 *wp = (u32x2 *)(tr + lane * 6);
+                wp[0] = u32x2{bw[0], bw[1]};
+                wp[1] = u32x2{bw[2], bw[3]};
+                wp[2] = u32x2{bw[4], bw[5]};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                pend_a = *(const u32x4 *)(tr + lane * 4);
+                const u32x2 pb = *(const u32x2 *)(tr + 256 + lane * 2);
+                pend_b = u32x4{pb.x, pb.y, 0, 0};
+                pend_oa = base + (u32)lane * 16u;
+                pend_ob = base + 1024u + (u32)lane * 8u;
+            } else { // 32 bytes per lane: bytes [0, 1024) and [1024, 2048) of the wave's 8 x 256
+                u32x4 *wp = (u32x4 *)(tr + lane * 8);
+                wp[0] = u32x4{bw[0], bw[1], bw[2], bw[3]};
+                wp[1] = u32x4{bw[4], bw[5], bw[6], bw[7]};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                pend_a = *(const u32x4 *)(tr + lane * 4);
+                pend_b = *(const u32x4 *)(tr + 256 + lane * 4);
+                pend_oa = base + (u32)lane * 16u;
+                pend_ob = base + 1024u + (u32)lane * 16u;
+            }
         }
         prevI = I;
     }
-    __builtin_nontemporal_store(pend_a, (u32x4 *)(sv_f + pend_oa));
-    __builtin_nontemporal_store(pend_b, (u32x2 *)(sv_f + pend_ob));
+    store_pend();
     if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1435,11 +1478,12 @@ int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *o
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
 {
     // edge values and their packed minimum must stay below 1024 (tag bits), the three-path sum below 256
-    return D == 192 && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095;
+    return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095;
 }
-size_t rsgm_vert3_xbuf_bytes(int B, int Wp)
+static int v3_xw(int D) { return D == 256 ? V3Rec<16>::XW : 16; }
+size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D)
 {
-    return ((size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * V3_XW) + V3_XW) * sizeof(u32); // + the record of zeros
+    return ((size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * v3_xw(D)) + v3_xw(D)) * sizeof(u32); // + the record of zeros
 }
 
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
@@ -1451,10 +1495,14 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     a.nwv = Wp / 8;
     a.nbg = (a.nwv + 3) / 4;
     a.vol_elems = (size_t)B * Hp * Wp * D;
-    VPPX_HIP(hipMemsetAsync(xbuf, 0, rsgm_vert3_xbuf_bytes(B, Wp), stream)); // no record of an earlier launch may match
-    sgm_vert3_kernel<<<dim3((unsigned)(2 * B * a.nbg)), 256, 0, stream>>>(a);
+    VPPX_HIP(hipMemsetAsync(xbuf, 0, rsgm_vert3_xbuf_bytes(B, Wp, D), stream)); // no record of an earlier launch may match
+    const dim3 grid((unsigned)(2 * B * a.nbg));
+    if (D == 64) sgm_vert3_kernel<8><<<grid, 256, 0, stream>>>(a);
+    else if (D == 128) sgm_vert3_kernel<16><<<grid, 256, 0, stream>>>(a);
+    else if (D == 192) sgm_vert3_kernel<24><<<grid, 256, 0, stream>>>(a);
+    else sgm_vert3_kernel<32><<<grid, 256, 0, stream>>>(a);
     VPPX_CHECK_LAUNCH();
-    (void)ctx; (void)D;
+    (void)ctx;
     return 0;
 }
 

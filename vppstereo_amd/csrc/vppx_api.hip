@@ -413,7 +413,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     // per launch on (540x960x192, ms per step 8-path / fused: B=4 2.20 / 2.26, B=8 3.74 / 3.27, B=16 6.94 / 5.90,
     // B=32 13.3 / 11.7); a context whose fused launch once lost its lock step never uses it again.
     bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
-    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
+    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192)))) {
         // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes?
         u32 *probe;
         bool ok = false;
@@ -424,7 +424,9 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         v3_ok = ok;
     }
     if (ctx->capturing && !ctx->vert3_probed) v3_ok = false; // (a first call inside a graph capture takes the 8-path layout)
-    const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8));
+    // (measured at B=32, 8-path / fused ms per step: D=64 7.5 / 7.5, D=128 10.6 / 9.2, D=192 13.3 / 11.7; 1536x2048x256 at
+    // B=8 28.1 / 28.9: the default takes the fused layout for D = 128 and 192)
+    const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192)));
     const bool vert = vert3 || (ctx->use_vert == 1 && elem_bytes == 1 && rsgm_vert_supported(g.D, maxp2) && g.D <= 192);
     ctx->last_vert = vert3 ? 3 : (vert ? 1 : 0);
     void *paths;
@@ -435,7 +437,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         u16 *gmin;
         if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 2, &paths))) return rc;
         if ((rc = ws_get(ctx, WS_SV, ncell * 2, &sv))) return rc;
-        if ((rc = ws_get(ctx, WS_VSTATE, vert3 ? rsgm_vert3_xbuf_bytes(g.B, g.Wp) : rsgm_vert_state_bytes(g.B, g.Wp, g.D), &gst))) return rc;
+        if ((rc = ws_get(ctx, WS_VSTATE, vert3 ? rsgm_vert3_xbuf_bytes(g.B, g.Wp, g.D) : rsgm_vert_state_bytes(g.B, g.Wp, g.D), &gst))) return rc;
         if ((rc = ws_get(ctx, WS_VMIN, vert3 ? 8 : rsgm_vert_min_elems(g.B, g.Wp), &gmin))) return rc;
         auto launch_vert = [&](hipStream_t st) -> int {
             if (!vert3) return rsgm_launch_vert(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, gst, gmin);

@@ -224,7 +224,7 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
 // band-marching vertical/diagonal paths (3 summed paths per pass, one byte per cell)
 int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev, bool *ok);
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2);
-size_t rsgm_vert3_xbuf_bytes(int B, int Wp);
+size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err);
 bool rsgm_vert_supported(int D, int maxp2);
