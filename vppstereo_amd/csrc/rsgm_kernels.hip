@@ -1478,7 +1478,9 @@ int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *o
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
 {
     // edge values and their packed minimum must stay below 1024 (tag bits), the three-path sum below 256
-    return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095;
+    // (record offsets are 32-bit byte offsets into one buffer: keep it below 1 GiB)
+    return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095 &&
+           (size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * 32) * sizeof(u32) < ((size_t)1 << 30);
 }
 static int v3_xw(int D) { return D == 256 ? V3Rec<16>::XW : 16; }
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D)
