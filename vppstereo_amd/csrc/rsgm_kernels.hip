@@ -1197,8 +1197,9 @@ struct Vert3Args {
 // sc1 bit (device scope: L1 bypassed, served by the XCD's L2) that the compiler can see, so it keeps their results
 // where they land and waits for them where they are used: v3_edges_issue starts them, the straight path's update
 // runs, v3_edges_complete checks the tags, polls again while a record is not there yet, and strips the tags.
-// One tag per 16-byte piece (its first dword; a lane's aligned 16-byte store and 16-byte load are single requests
-// to one cache line, so a piece is seen whole or not at all) and one on the minimum.
+// Tags on the first and the last dword of every 16-byte piece (a lane's aligned 16-byte store and 16-byte load are
+// single requests to one cache line, so a piece is seen whole or not at all; both ends are checked all the same)
+// and on the minimum.
 template <int NP>
 struct V3Edge {
     u32x4 p[NP / 4]; // the NP pairs in 16-byte pieces
@@ -1219,7 +1220,7 @@ __device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int
     for (;;) {
         u32 bad = r.m ^ T;
 #pragma unroll
-        for (int k = 0; k < NP / 4; k++) bad |= r.p[k].x ^ T;
+        for (int k = 0; k < NP / 4; k++) bad |= (r.p[k].x ^ T) | (r.p[k].w ^ T);
         const bool ok = !want || (bad & V3_TAGMASK) == 0;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         if (++spins >= V3_SPIN_LIMIT) {
@@ -1230,7 +1231,10 @@ __device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int
         v3_edges_issue<NP>(xr, off, r);
     }
 #pragma unroll
-    for (int k = 0; k < NP / 4; k++) r.p[k].x &= ~V3_TAGMASK;
+    for (int k = 0; k < NP / 4; k++) {
+        r.p[k].x &= ~V3_TAGMASK;
+        r.p[k].w &= ~V3_TAGMASK;
+    }
     r.m &= ~V3_TAGMASK;
 }
 
@@ -1382,14 +1386,14 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         if (t + 1 < Hp && g == 7 && has_right) { // the last pixel's state goes to the right wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (0 * 8 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], L1[i + 3]};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], L1[i + 3] | Tout};
             q[NP] = mn1 | Tout;
         }
         sgm_update_split<NP, 8>(L2, C, P1pk, P2c, mn2, first, last);
         if (t + 1 < Hp && g == 0 && has_left) { // the first pixel's state goes to the left wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (1 * 8 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], L2[i + 3]};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], L2[i + 3] | Tout};
             q[NP] = mn2 | Tout;
         }
         // ---- operands of the next row.  Issued this late on purpose: in flight during the updates they cost 26 more
