@@ -441,7 +441,15 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         if ((rc = ws_get(ctx, WS_VMIN, vert3 ? 8 : rsgm_vert_min_elems(g.B, g.Wp), &gmin))) return rc;
         auto launch_vert = [&](hipStream_t st) -> int {
             if (!vert3) return rsgm_launch_vert(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, gst, gmin);
-            if (!ctx->vert3_err && hipHostMalloc((void **)&ctx->vert3_err, 64, hipHostMallocMapped) == hipSuccess) ctx->vert3_err[0] = 0;
+            if (!ctx->vert3_err) { // the word a wave that gives up reports through: no fused launch without it
+                if (hipHostMalloc((void **)&ctx->vert3_err, 64, hipHostMallocMapped) != hipSuccess) {
+                    ctx->vert3_err = nullptr;
+                    (void)hipGetLastError();
+                    vppx_set_error("could not allocate the pinned status word of the fused aggregation kernel");
+                    return VPPX_E_HIP;
+                }
+                ctx->vert3_err[0] = 0;
+            }
             // event pairs around the fused launch: what bench.py prices as the dominant kernel
             const bool timed = !ctx->capturing && st == ctx->stream;
             if (timed && !ctx->agg_ev_created) {
