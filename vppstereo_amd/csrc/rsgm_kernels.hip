@@ -679,6 +679,14 @@ __device__ __forceinline__ void run_line(const u8 *gray_f, const u32 *cl_f, cons
     st.prevI = A.I;
     const int dpix = dys * Wp + dxs; // pixel index advance per step (before the diagonal wrap)
     (void)y;
+    // Enter the loop with the first operands "used" (no load in flight).  hipcc's s_waitcnt pass merges the counter
+    // state of the loop entry with that of the back edge; with loads pending on entry, the merged state keeps waits in
+    // the loop header that, on the back edge, drain the volume store issued a few instructions earlier: a full store
+    // round trip exposed every iteration.  (Worth 0 on the 8-direction launch, whose waves hide it; the W/E launch of
+    // the fused layout is a latency chain per line.)
+#pragma unroll
+    for (int i = 0; i < (FROM_DSI ? DPL / 2 : DPL); i++) asm volatile("" ::"v"(A.w[i]));
+    asm volatile("" ::"v"(A.clv), "v"(A.I));
     for (int t = 0; t < nsteps; t += 2) {
         // position of step t+1 (clamped at the end of the line: a harmless reload).  Only diagonal lines can
         // leave the image sideways: they wrap to the other border of the same row.
