@@ -118,3 +118,20 @@ def test_cross_call_pipelining_keeps_results_and_stream_order():
         for i in range(len(batches)):
             assert torch.equal(out_bufs[i][rep], refs[i]), (rep, i)
             assert float(sums[rep * len(batches) + i]) == float(refs[i].double().sum()), (rep, i)
+    # other entry points between pipelined calls use the same workspace on the launch stream: the next front stage has
+    # to wait for them (the library drops its "previous aggregation done" shortcut on any other call)
+    l0, r0, h0 = batches[0]
+    l2, r2, h2 = batches[2]
+    ref_lv, ref_rv = ref_eng.vpp(l2, r2, h2, seed=9)
+    ref_sep = ref_eng.rsgm(l2, ref_lv, ref_rv, dmax=192).clone()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        occ = eng.occlusion_heuristic(h0, out=occ_bufs[0])
+        a = eng.vpp_rsgm(l0, r0, h0, g_occ=occ, out=out_bufs[0][0], seed=0, rsgm_kw=dict(dmax=192))
+        lv, rv = eng.vpp(l2, r2, h2, seed=9)                     # not pipelined: VPP workspace, launch stream
+        sep = eng.rsgm(l2, lv, rv, out=out_bufs[2][0], dmax=192)  # not pipelined: gray / census / volumes, launch stream
+        occ = eng.occlusion_heuristic(h0, out=occ_bufs[0])
+        b = eng.vpp_rsgm(l0, r0, h0, g_occ=occ, out=out_bufs[0][1], seed=0, rsgm_kw=dict(dmax=192))
+        torch.cuda.synchronize()
+        assert torch.equal(a, refs[0]) and torch.equal(b, refs[0]) and torch.equal(sep, ref_sep), rep
+        assert torch.equal(lv, ref_lv) and torch.equal(rv, ref_rv), rep

@@ -41,7 +41,13 @@ struct DevGuard {
 };
 #define VPPX_ENTER(ctx)                                                                                              \
     if (!(ctx)) { vppx_set_error("context is NULL (vppx_create failed? there is no CPU fallback)"); return VPPX_E_NO_DEVICE; } \
-    DevGuard dev_guard_((ctx)->device)
+    DevGuard dev_guard_((ctx)->device);                                                                                  \
+    /* cross-call pipelining: any entry point but the two pipelined ones may queue work that touches the front stage's   \
+       buffers, so the next front stage must wait for the whole launch stream again (PIPE_KEEP restores the flag) */      \
+    const bool pipe_had_agg_done_ = (ctx)->have_agg_done;                                                                 \
+    (ctx)->have_agg_done = false;                                                                                         \
+    (void)pipe_had_agg_done_
+#define VPPX_PIPE_KEEP(ctx) (ctx)->have_agg_done = pipe_had_agg_done_
 
 extern "C" void vppx_vpp_params_default(VppxVppParams *p)
 {
@@ -215,7 +221,10 @@ extern "C" int vppx_set_stream(vppx_ctx *ctx, void *hip_stream)
 {
     VPPX_ENTER(ctx);
     if (hip_stream != nullptr) {
-        if (ctx->stream == (hipStream_t)hip_stream && !ctx->own_stream && !ctx->legacy_stream) return 0; // already bound
+        if (ctx->stream == (hipStream_t)hip_stream && !ctx->own_stream && !ctx->legacy_stream) { // already bound
+            VPPX_PIPE_KEEP(ctx);
+            return 0;
+        }
         int rc = release_own_stream(ctx);
         if (rc) return rc;
         ctx->stream = (hipStream_t)hip_stream;
@@ -233,7 +242,10 @@ extern "C" int vppx_set_stream(vppx_ctx *ctx, void *hip_stream)
 extern "C" int vppx_set_stream_legacy(vppx_ctx *ctx)
 {
     VPPX_ENTER(ctx);
-    if (ctx->legacy_stream) return 0;
+    if (ctx->legacy_stream) {
+        VPPX_PIPE_KEEP(ctx);
+        return 0;
+    }
     int rc = release_own_stream(ctx);
     if (rc) return rc;
     ctx->stream = nullptr; // hipStream_t 0 = the legacy default stream
@@ -896,6 +908,7 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
 {
     int rc;
     VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
     if (!vp || !rp || !left || !right || !g || !disp_out) { vppx_set_error("vppx_vpp_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_frames(B, H, W, C))) return rc;
     if ((rc = check_vpp_params(*vp))) return rc;
@@ -1091,6 +1104,7 @@ extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, 
 {
     int rc;
     VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
     if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
     const size_t n = (size_t)B * H * W;
     float *omap;
