@@ -1491,7 +1491,13 @@ bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
 {
     // edge values and their packed minimum must stay below 1024 (tag bits), the three-path sum below 256
     // (record offsets are 32-bit byte offsets into one buffer: keep it below 1 GiB)
+    // All blocks of a (frame, pass) group must be resident together, with room to spare for the blocks of the next group
+    // that arrive early: at most 3/4 of the block slots of one XCD (32 CUs x 8 / 5 / 4 / 3 blocks for D = 64 .. 256:
+    // 56 / 84 / 116 / 142 VGPRs).  Wider frames take the 8-path layout.
+    const int blocks_per_cu = D == 64 ? 8 : (D == 128 ? 5 : (D == 192 ? 4 : 3));
+    const int nbg = (Wp / 8 + 3) / 4;
     return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095 &&
+           nbg <= 32 * blocks_per_cu * 3 / 4 &&
            (size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * 32) * sizeof(u32) < ((size_t)1 << 30);
 }
 static int v3_xw(int D) { return D == 256 ? V3Rec<16>::XW : 16; }
