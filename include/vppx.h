@@ -269,8 +269,10 @@ int vppx_time_aggregate_frames(vppx_ctx *ctx);
 /* Same for one part of the stage: 1 = horizontal-path line kernel, 2 = the band launches of the
  * vertical/diagonal paths (fast path only). */
 int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, float *ms_out);
-/* 1 if the last vppx_rsgm_dev call used the band-marching fast path for the 6 non-horizontal
- * paths, 0 if all 8 paths ran in the line-parallel kernel. */
+/* Aggregation layout of the last fused / rsgm call: 0 = all 8 paths in the line-parallel kernel, 3 = W and E
+ * line-parallel + N/NW/NE and S/SW/SE fused three at a time in the lock-step kernel (default for D = 128 / 192 from 8
+ * frames per call on; environment VPPX_VERT = 0 / 3 forces a layout), 1 = the round-1 band-marching experiment
+ * (VPPX_VERT = 1).  All layouts give identical results. */
 int vppx_uses_vert(vppx_ctx *ctx);
 /* Per-stage hipEvent timing of the last vppx_vpp_rsgm_dev/vppx_rsgm_dev call when stage
  * timing is enabled: fills ms[0..n) and returns the number of stages; names via
