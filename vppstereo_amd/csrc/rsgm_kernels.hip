@@ -1367,6 +1367,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         // ---- straight path: needs nobody else's state
         sgm_update_split<NP, 8>(L0, C, P1pk, P2a, mn0, first, last);
         v3_edges_complete<NP>(xrsrc, eoff, want, Tin, er, dead);
+        __builtin_amdgcn_s_setprio(2); // from here to the second publish the neighbours wait for this wave
         {
             u32 e[NP + 1];
 #pragma unroll
@@ -1404,6 +1405,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
             for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], L2[i + 3] | Tout};
             q[NP] = mn2 | Tout;
         }
+        __builtin_amdgcn_s_setprio(0);
         // ---- operands of the next row.  Issued this late on purpose: in flight during the updates they cost 26 more
         // live VGPRs (156 instead of 127, 3 waves per SIMD instead of 4); the shorter distance to their use is covered
         // by the fourth wave
