@@ -43,7 +43,12 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 AGG_BYTES_PER_CELL = 10.0        # aggregation share of the 16 B/cell algorithmic bytes
 PATH_BYTES_PER_CELL = 16.0       # whole path, + 50 B/pixel
 PATH_BYTES_PER_PIXEL = 50.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+N_SIMD = 1024                    # 256 CUs x 4 SIMDs
+# average issue cost of one VALU wave-instruction of the fused aggregation kernel's row loop: its mix of full-rate (~2.5
+# cycles) and half-rate (~4 cycles: VOP3P, three-operand VOP3, v_bcnt, DPP) instructions priced with the rates
+# tools/valu_bench.hip measured on gfx950 (profiles/r02_valu_issue_rates.txt)
+VALU_CYCLES_PER_INST = 3.3
 
 
 def parse(argv=None):
@@ -68,6 +73,8 @@ def parse(argv=None):
     ap.add_argument("--uniform-random", action="store_true",
                     help="uniform-random u8 images and hint values (the variant SURVEY section 6 timed on the CPU) "
                          "instead of the textured scenes; GPU timing only")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the bounded runs of the other BASELINE configurations (cfg 3 KITTI B=32, cfg 5 1536x2048x256 B=8)")
     ap.add_argument("--spawn-check", action="store_true",
                     help="rank processes only form the process group (gloo, CPU) and report the frame plan: launcher self-test")
     return ap.parse_args(argv)
@@ -232,6 +239,61 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+class SclkSampler:
+    """Shader clock while the timed region runs, read from the driver's sysfs table (pp_dpm_sclk: the active level is
+    starred) by a background thread; None when the box does not expose it."""
+
+    def __init__(self, dev_index=0, period=0.02):
+        import glob
+        import threading
+        self.samples, self._stop, self._path = [], threading.Event(), None
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cands:
+            self._path = cands[min(dev_index, len(cands) - 1)]
+        self._period = period
+        self._thr = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            with open(self._path) as f:
+                for line in f:
+                    if "*" in line:
+                        return float(line.split(":")[1].replace("Mhz", "").replace("MHz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(self._period)
+
+    def __enter__(self):
+        if self._path:
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._path:
+            self._thr.join(timeout=1.0)
+
+    def mhz(self):
+        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
+
+
+def load_pmc():
+    """The committed PMC profile, or None when it was taken from other kernel sources."""
+    try:
+        with open(PMC_PROFILE) as f:
+            pmc = json.load(f)
+    except Exception:
+        return None
+    return pmc if pmc.get("kernel_source_sha") == kernel_source_sha() else None
+
+
 def pmc_view(agg_frames, kernel_ms, kernel="sgm_paths_kernel"):
     """PMC numbers of the aggregation kernel from the committed profile, or None when the profile was taken from
     other kernel sources / another batch size."""
@@ -252,6 +314,40 @@ def pmc_view(agg_frames, kernel_ms, kernel="sgm_paths_kernel"):
     if "hbm_GB_per_launch" in k and kernel_ms > 0:
         out["hbm_frac_of_peak"] = round(k["hbm_GB_per_launch"] / (kernel_ms * 1e-3) / HBM_PEAK_GBS, 4)
     return out
+
+
+def other_config(eng, torch, synth, name, h, w, d, p, batch, steps=4, warmup=2):
+    """One of the other BASELINE.json configurations, same loop as the headline (mask, overlap, inputs resident), bounded:
+    `batch` distinct synthetic scenes, a few steps.  Parity at these sizes: tests/test_gpu_fullsize.py, test_gpu_headline.py."""
+    import numpy as np
+    dev = eng.device
+    b = synth.make_batch(batch, h, w, d, p, seed=4321)
+    left, right, hints = (torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints"))
+    occ = torch.empty((batch, h, w), dtype=torch.uint8, device=dev)
+    outs = [torch.empty((batch, h, w), dtype=torch.float32, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    ev.record()
+    torch.cuda.synchronize()
+
+    def one(k):
+        eng.vpp_rsgm(left, right, hints, g_occ="occlusion_heuristic", occ_out=occ, out=outs[k & 1], seed=1,
+                     rsgm_kw=dict(dmax=d, subpixel=1), inputs_ready=ev)
+
+    for k in range(warmup):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(k)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    eng.status()
+    mdisp = batch * h * w * d / ms / 1e3
+    return {"config": name, "H": h, "W": w, "D": d, "hint_density": p, "frames_per_step": batch, "steps": steps,
+            "ms_per_step": round(ms, 3), "Mdisparities_per_s": round(mdisp, 1),
+            "roofline_frac": round(mdisp * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / d) / 1e9 / HBM_PEAK_GBS, 4),
+            "aggregation_layout": eng.uses_vert()}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -299,8 +395,8 @@ def run_rank(args):
     B = args.batch
     plan = frame_plan(B, rank, world)
     n_total, lo, seed0 = plan["n_total"], plan["lo"], plan["seed0"]
-    # synthetic frames: a few distinct scenes tiled over the batch (generation is host-side numpy)
-    n_unique = min(B, 4)
+    # synthetic frames: every frame of the batch is its own scene (generation is host-side numpy, ~0.4 s per frame)
+    n_unique = B
     if args.uniform_random:
         trip = [synth.uniform_random_pair(H, W, D, P_HINTS, seed=lo + i) for i in range(n_unique)]
         base = {"left": np.stack([t[0] for t in trip]), "right": np.stack([t[1] for t in trip]),
@@ -319,9 +415,17 @@ def run_rank(args):
     pending = [None] * n_out  # gathers in flight, one per output buffer
     nstep = [0]
 
+    # the inputs are resident: everything uploaded above is complete once this event is (it lets the pipelined front stage
+    # of a step start under the previous step's tail instead of waiting for the whole launch stream: vppx_inputs_ready_event)
+    torch.cuda.synchronize()
+    ev_ready = torch.cuda.Event()
+    ev_ready.record()
+    torch.cuda.synchronize()
+
     def local_step(buf, use_occ=True, lft=left, rgt=right, hnt=hints, occb=occ_buf):
-        occ = eng.occlusion_heuristic(hnt, out=occb) if use_occ else None   # test.py:154 (--maskocc)
-        eng.vpp_rsgm(lft, rgt, hnt, g_occ=occ, out=buf, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1))
+        # test.py:154 (--maskocc) + :158-225 in one call: mask -> VPP -> rSGM; the mask is delivered to the caller as well
+        eng.vpp_rsgm(lft, rgt, hnt, g_occ="occlusion_heuristic" if use_occ else None, occ_out=occb if use_occ else None,
+                     out=buf, seed=seed0, rsgm_kw=dict(dmax=D, subpixel=1), inputs_ready=ev_ready)
         return buf
 
     use_occ = not args.no_occ
@@ -381,7 +485,9 @@ def run_rank(args):
         step()
     drain()
     eng.agg_kernel_ms(0)  # reset: the hipEvent pairs around the aggregation launches of the timed steps only
-    dt_local = timed(args.steps, step)
+    with SclkSampler(dev_index) as sclk:
+        dt_local = timed(args.steps, step)
+    eng.status()   # raises if a fused aggregation launch of the timed region lost its lock step (its disparities would be void)
     dt = dt_local
     rank_ms = [dt_local / args.steps * 1e3]
     if world > 1:
@@ -393,6 +499,20 @@ def run_rank(args):
         dt = max(float(x.item()) for x in allt)
     if args.graph:
         assert eng.graph_replays() > 0, "--graph was given but no call was served by a graph replay"
+    # the same steps with the cross-step overlap off (every rank: `timed` has barriers)
+    ms_unpipelined = None
+    if not (args.no_pipeline or args.graph):
+        eng.set_pipeline(False)
+        n_unp = max(2, min(5, args.steps))
+        step()
+        drain()
+        ms_unpipelined = timed(n_unp, step) / n_unp * 1e3
+        if world > 1:
+            t = torch.tensor([ms_unpipelined], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_unpipelined = float(t.item())
+        eng.status()
+        eng.set_pipeline(True)
 
     ms_per_step = dt / args.steps * 1e3
     value = n_total * H * W * D * args.steps / dt / 1e6
@@ -443,11 +563,47 @@ def run_rank(args):
         stages = eng.stage_ms()
         eng.enable_stage_timing(False)
         pipeline_gbs = value * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / D) / 1e9
+        # ---- the dominant kernel as it is: issue-bound, so its own bound is the VALU issue time, not a byte count ----
+        pmc_all = load_pmc()
+        pmc_ok = bool(pmc_all) and pmc_all.get("batch") == agg_frames and (pmc_all.get("H"), pmc_all.get("W"), pmc_all.get("D")) == (H, W, D)
+        step_traffic = round(pmc_all["hbm_GB_per_step"], 3) if pmc_ok and pmc_all.get("hbm_GB_per_step") else None
+        sclk_mhz = sclk.mhz()
+        valu = None
+        if pmc and pmc.get("SQ_INSTS_VALU"):
+            # shader clock: sampled from sysfs during the timed region; else what the profile run measured
+            # (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / the kernel's duration in that run)
+            clk = sclk_mhz or pmc.get("sclk_mhz_profiled")
+            if clk:
+                floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (N_SIMD * clk * 1e6) * 1e3
+                valu = {"SQ_INSTS_VALU_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+                        "simds": N_SIMD, "sclk_mhz": clk, "sclk_source": "sysfs pp_dpm_sclk during the timed region" if sclk_mhz else "profile run (GRBM_GUI_ACTIVE)",
+                        "issue_floor_ms": round(floor_ms, 3), "frac_of_issue_floor": round(floor_ms / agg_ms, 4),
+                        "wave_cycles_active_issuewait_memwait": [pmc.get("sq_active_inst_any_frac_of_wave_cycles"),
+                                                                 pmc.get("sq_wait_inst_any_frac_of_wave_cycles"),
+                                                                 pmc.get("sq_wait_any_frac_of_wave_cycles")]}
+        dom = {"kernel": ("sgm_vert3_kernel (N, NW, NE and S, SW, SE fused three at a time: 6 of the 8 aggregation paths)"
+                          if fused else "sgm_paths_kernel (8-path aggregation)"),
+               "bound": "valu",
+               "kernel_ms": round(agg_ms, 4), "kernel_launches_timed": agg_n, "kernel_ms_back_to_back": round(agg_ms_b2b, 4),
+               "share_of_step": round(agg_ms / ms_per_step, 3),
+               "valu": valu,
+               "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None,
+               "traffic_unit": "GB per launch (PMC)",
+               "hbm_frac_of_peak": pmc.get("hbm_frac_of_peak") if pmc else None,
+               "convention_frac": round(achieved / HBM_PEAK_GBS, 4),
+               "convention": f"{agg_bytes} B/cell = SURVEY 8d's 10 B/cell of the 8-path aggregation, pro rata for the paths this launch "
+                             f"carries: {round(cells_launch * agg_bytes / 1e9, 3)} GB per launch / kernel_ms vs 8 TB/s (a byte-count "
+                             "convention, not a utilisation: see valu and hbm_frac_of_peak)",
+               "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": round(we_ms, 4)} if fused else None),
+               "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,
+               "sclk_mhz_during_timed_region": sclk_mhz,
+               "pmc": pmc}
         occ_txt = "occlusion heuristic + " if use_occ else ""
         result = {
             "metric": f"Mdisparities/s (HxWxD / s) VPP+rSGM at {H}x{W}xD={D}",
             "value": round(value, 1), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step_unpipelined": round(ms_unpipelined, 3) if ms_unpipelined else None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u16",
             "data": "synthetic (uniform random u8)" if args.uniform_random else "synthetic",
             "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, {occ_txt}VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
@@ -455,29 +611,28 @@ def run_rank(args):
                        "H": H, "W": W, "D": D, "hint_density": P_HINTS, "g_occ": "occlusion_heuristic" if use_occ else None,
                        "cross_step_overlap": (None if (args.no_pipeline or args.graph) else
                                               "front stage of step k+1 (occlusion heuristic, VPP, pad+gray, census) on a second "
-                                              "stream under the sum/WTA and post kernels of step k")},
+                                              "stream under the sum/WTA and post kernels of step k; inputs are resident and declared "
+                                              "ready (vppx_inputs_ready_event), outputs are delivered in launch-stream order; "
+                                              "ms_per_step_unpipelined is the same loop with the overlap off")},
             "ranks": {"launched": args.gpus, "seen": dist.get_world_size() if world > 1 else 1,
                       "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
                       "ms_per_step_per_rank": [round(x, 3) for x in rank_ms]},
-            "roofline": {"bound": "valu",
-                         "kernel": ("sgm_vert3_kernel (N, NW, NE and S, SW, SE fused three at a time: 6 of the 8 aggregation paths)"
-                                    if fused else "sgm_paths_kernel (8-path aggregation)"),
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None,
-                         "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; null unless the committed profile "
-                                         "was taken from these kernel sources at this batch size)",
-                         "pmc": pmc,
-                         "algorithmic_GB_per_launch": round(cells_launch * agg_bytes / 1e9, 3),
-                         "kernel_ms": round(agg_ms, 4), "kernel_launches_timed": agg_n,
-                         "kernel_ms_back_to_back": round(agg_ms_b2b, 4), "bytes_per_cell": agg_bytes,
-                         "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": round(we_ms, 4)} if fused else None),
-                         "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,
-                         "note": "HBM-roofline convention of SURVEY 8d (10 B/cell for the 8-path aggregation, pro rata for the paths "
-                                 "a launch carries); the kernel itself is issue-bound (DESIGN section 6), hence bound = valu"},
+            # SURVEY 8d's roofline of this path: Mdisp/s x (16 B per cell + 50 B per pixel) against the HBM peak.  This is the
+            # figure north_star's ">= 60 %" is about; it prices the REFERENCE's dataflow, the build moves less (traffic).
+            "roofline": {"bound": "hbm",
+                         "what": "whole step at SURVEY 8d's algorithmic bytes, H*W*(16*D + 50) B per frame, vs the HBM3E peak",
+                         "achieved": round(pipeline_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
+                         "frac_unpipelined": (round(pipeline_gbs * ms_per_step / ms_unpipelined / HBM_PEAK_GBS, 4) if ms_unpipelined else None),
+                         "algorithmic_GB_per_step": round(n_total / world * H * W * (PATH_BYTES_PER_CELL * D + PATH_BYTES_PER_PIXEL) / 1e9, 3),
+                         "traffic": step_traffic,
+                         "traffic_unit": "GB of real HBM traffic per step and GPU, all kernels (PMC FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                         "rocprofv3 passes; null unless the committed profile was taken from these kernel sources)",
+                         "hbm_frac_of_peak": (round(step_traffic / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4) if step_traffic else None),
+                         "dominant_kernel": dom},
             "pipeline_roofline": {"bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,
-                                  "achieved_GBps": round(pipeline_gbs, 1),
-                                  "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4)},
+                                  "achieved_GBps": round(pipeline_gbs, 1), "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
+                                  "note": "same figure as roofline (kept under its round-2 name)"},
             ("ms_per_step_without_g_occ" if use_occ else "ms_per_step_with_g_occ"): other,
             "b1": {"ms_per_frame": round(b1_ms, 4), "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),
                    "what": "one frame per call (B=1), host-paced loop of 20 calls, same stages as the step"
@@ -499,6 +654,15 @@ def run_rank(args):
                 result["cpu_baseline_all_cores"] = cpu_baseline_parallel()
         else:
             result["cpu_baseline"] = None
+        if world == 1 and not args.no_other_configs and not args.shape and not args.uniform_random and not args.graph:
+            # the other BASELINE.json configurations on this one GPU (their multi-GPU form shards frames: section 7 of DESIGN.md)
+            result["other_configs"] = [
+                other_config(eng, torch, synth, "cfg3: KITTI-sized 375x1242 stream, 5% hints, D=192, 32 frames per step", 375, 1242, 192, 0.05, 32),
+                other_config(eng, torch, synth, "cfg5: 1536x2048 indoor pairs, 1% hints, D=256, 8 frames per step", 1536, 2048, 256, 0.01, 8, steps=3, warmup=1),
+                {"config": "cfg2 literal: one 540x960 pair per call, D=192", "ms_per_frame": round(b1_ms, 4),
+                 "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),
+                 "roofline_frac": round(H * W * D / b1_ms / 1e3 * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / D) / 1e9 / HBM_PEAK_GBS, 4)},
+            ]
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

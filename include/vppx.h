@@ -103,6 +103,14 @@ typedef struct VppxRsgmParams {
     int32_t reserved0;
 } VppxRsgmParams;
 
+/* Parameters of occlusion_heuristic (filter.py:246; defaults in brackets). */
+typedef struct VppxOccParams {
+    int32_t rx, ry;      /* [9] [7]   */
+    double l, g;         /* [2] [0.4375] */
+    double th_conf;      /* [1]   */
+    double th_filter;    /* [0.1] */
+} VppxOccParams;
+
 typedef struct vppx_ctx vppx_ctx; /* opaque: device, stream, workspace arena */
 
 /* ---- library / context ------------------------------------------------------------ */
@@ -110,6 +118,7 @@ int vppx_version(void);
 const char *vppx_last_error(void);
 void vppx_vpp_params_default(VppxVppParams *p);
 void vppx_rsgm_params_default(VppxRsgmParams *p);
+void vppx_occ_params_default(VppxOccParams *p);
 
 /* Create a context on HIP device `device` (-1 = current device).  One context per
  * process/GPU; not thread-safe (the reference is single-threaded: rsgm.py:44). */
@@ -122,15 +131,40 @@ int vppx_set_stream(vppx_ctx *ctx, void *hip_stream);
  * vppx_set_stream reads as "own stream").  All work is then ordered with the caller's default-stream work. */
 int vppx_set_stream_legacy(vppx_ctx *ctx);
 
-/* Cross-call pipelining for streams of batches through vppx_occlusion_heuristic_dev + vppx_vpp_rsgm_dev: with `on`, the
- * front stage of a call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the
- * PREVIOUS call's aggregation is done, i.e. next to that call's sum / WTA and post kernels.  Outputs keep the launch
- * stream's order (it waits for the front stage).  Inputs must be ready when the call is made: work queued on the launch
- * stream after the previous call is NOT waited for by the front stage; likewise the buffers the front stage writes
- * (conf_out, l_vpp, r_vpp) must not be memory that earlier queued work still has to read.  Off by default; ignored during graph capture,
- * stage timing and for sub-stream parts.  (No reference counterpart: test.py handles one pair at a time.) */
+/* Cross-call pipelining for streams of batches through vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev: with `on`, the front
+ * stage of a call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the PREVIOUS call's
+ * aggregation is done, i.e. next to that call's sum / WTA and post kernels.  Safe by construction:
+ *   - outputs keep the launch stream's order: the launch stream waits for the front stage, and everything the front stage
+ *     produces for the caller (conf_out, l_vpp, r_vpp) is computed into library-owned buffers and copied to the caller's
+ *     memory ON THE LAUNCH STREAM -- the front stream never writes caller memory, so buffers allocated per call by a
+ *     stream-ordered allocator (torch's) are fine;
+ *   - inputs: the front stage waits for an event.  By default the library records it on the launch stream when the call
+ *     is made, i.e. the front stage waits for everything queued before the call (correct for any caller; no overlap then).
+ *     A caller whose inputs are ready earlier -- resident frames, a loader running on its own stream -- says so with
+ *     vppx_inputs_ready_event: the front stage of the NEXT call then waits for that event instead and overlaps the
+ *     previous call's tail.
+ * Any other entry point called in between uses the same workspace on the launch stream and makes the next front stage
+ * wait for the whole launch stream again.  Off by default; ignored during graph capture, stage timing and for sub-stream
+ * parts.  (No reference counterpart: test.py handles one pair at a time.) */
 int vppx_set_pipeline(vppx_ctx *ctx, int on);
+/* One-shot: `hip_event` (a hipEvent_t the caller recorded on the stream that produced them) completes when ALL inputs of
+ * the next vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev call (left, right, g, g_occ) are ready.  NULL withdraws it.  Without
+ * pipelining the call runs on the launch stream and the event is simply waited for there. */
+int vppx_inputs_ready_event(vppx_ctx *ctx, void *hip_event);
+/* Wait for everything queued on the context's stream.  Returns VPPX_E_HIP (message in vppx_last_error) when a fused
+ * aggregation launch that has finished by then lost its lock step (see vppx_status). */
 int vppx_synchronize(vppx_ctx *ctx);
+/* Health of the asynchronous hot path, non-blocking.  The fused aggregation kernel (vppx_uses_vert() == 3) hands
+ * diagonal path state between neighbouring waves in lock step; every wait is bounded (VPPX_V3_TIMEOUT_MS, default 250 ms
+ * of wall clock per wait), and a wave that gives up marks its launch: the disparities of that call are void.  The mark is
+ * reported -- VPPX_E_HIP, once -- by whichever of these looks first: vppx_status, vppx_synchronize, the next
+ * vppx_occlusion_heuristic_dev / vppx_vpp_rsgm_dev / vppx_rsgm_dev call, or vppx_rsgm_host, which instead repeats its own
+ * aggregation on the line-parallel kernel and returns correct results.  From then on the context aggregates with the
+ * line-parallel kernel only.  After the caller has synchronised the stream (by any means) a 0 from vppx_status covers
+ * every call made so far.  (No reference counterpart: aggregate_SSE, rsgm.py:61, is synchronous.) */
+int vppx_status(vppx_ctx *ctx);
+/* Number of fused launches that reported a lost lock step on this context so far. */
+long vppx_lockstep_failures(vppx_ctx *ctx);
 /* Bytes of device workspace currently held by the context. */
 size_t vppx_workspace_bytes(const vppx_ctx *ctx);
 /* Name of the HIP device the context runs on (e.g. "AMD Instinct MI355X"). */
@@ -204,6 +238,13 @@ int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, i
 int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W, int C,
                       const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
                       uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out);
+
+/* The same with the occlusion mask computed on the way (test.py:154 --maskocc, then :158-225): g_occ =
+ * occlusion_heuristic(g, op)[1] never leaves the library between the two stages.  conf_out (uint8 [B,H,W], may be NULL)
+ * receives the mask.  This is the entry point bench.py times. */
+int vppx_occ_vpp_rsgm_dev(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B,
+                          int H, int W, int C, const uint8_t *left, const uint8_t *right, const float *g, uint8_t *conf_out,
+                          uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out);
 
 /* ---- hand-off to the deep front-ends (test.py:179-200) -------------------------------------- */
 /* uint8 [B,H,W,C] (device) -> [B,C,Hq,Wq] float32 (dst_is_bf16 = 0) or bfloat16 (1) in [0,1]

@@ -1,0 +1,302 @@
+"""GPU: the launch shape bench.py times, tested as it is timed -- 32 frames per call at full size, the occlusion mask
+from occlusion_heuristic, cross-call pipelining on, consecutive steps without a synchronisation in between, 32
+DISTINCT scenes -- plus the failure path of the fused aggregation kernel: a lost lock step must be reported by the
+synchronisation of the SAME call (vppx_synchronize / vppx_status), never surface as wrong disparities with rc 0
+(the reference's aggregate_SSE, rsgm.py:61, is synchronous and cannot do that), and the context must carry on,
+correctly, on the line-parallel kernel."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(**env):
+    """A fresh Engine created under the given environment (the context reads its knobs at creation)."""
+    from vppstereo_amd.engine import Engine
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        return Engine()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _dev(eng, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+
+
+@pytest.mark.parametrize("H,W,p", [(540, 960, 0.03), (375, 1242, 0.05)])
+def test_benchmarked_launch_shape_b32_mask_pipelined_distinct_scenes(H, W, p):
+    """B = 32, D = 192, g_occ from occlusion_heuristic, set_pipeline(True), three consecutive steps with nothing but the
+    calls themselves between them: every frame of every step equals the unpipelined 8-path layout bit for bit, the
+    masks and patterned pairs too, and the first four frames equal the CPU oracle."""
+    import torch
+    B, D, STEPS = 32, 192, 3
+    eng = _engine()
+    eng.set_pipeline(True)
+    ref = _engine(VPPX_VERT=0)
+    b = synth.make_batch(B, H, W, D, p, seed=4242 + H)
+    left, right, hints = (_dev(eng, b[k]) for k in ("left", "right", "hints"))
+    occ_buf = torch.empty((B, H, W), dtype=torch.uint8, device=eng.device)
+    outs = [torch.empty((B, H, W), dtype=torch.float32, device=eng.device) for _ in range(STEPS)]
+    lvs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=eng.device) for _ in range(STEPS)]
+    rvs = [torch.empty_like(lvs[0]) for _ in range(STEPS)]
+    torch.cuda.synchronize()
+    ev_ready = torch.cuda.Event()   # the inputs are resident (bench.py says the same to the library)
+    ev_ready.record()
+    torch.cuda.synchronize()
+    for s in range(STEPS):      # the bench loop (bench.py local_step): no synchronisation between the steps
+        eng.vpp_rsgm(left, right, hints, g_occ="occlusion_heuristic", occ_out=occ_buf, out=outs[s], l_vpp=lvs[s], r_vpp=rvs[s],
+                     seed=11 + 100 * s, rsgm_kw=dict(dmax=D, subpixel=1), inputs_ready=ev_ready)
+    eng.synchronize()           # raises if a fused launch lost its lock step
+    assert eng.uses_vert() == 3
+    occ_ref = ref.occlusion_heuristic(hints)
+    for s in range(STEPS):
+        lv = torch.empty_like(lvs[0])
+        rv = torch.empty_like(lvs[0])
+        want = ref.vpp_rsgm(left, right, hints, g_occ=occ_ref, l_vpp=lv, r_vpp=rv, seed=11 + 100 * s, rsgm_kw=dict(dmax=D, subpixel=1))
+        ref.synchronize()
+        assert ref.uses_vert() == 0
+        assert torch.equal(occ_buf, occ_ref)
+        assert torch.equal(lvs[s], lv) and torch.equal(rvs[s], rv), s
+        bad = (outs[s] != want).flatten(1).any(1).nonzero().flatten().tolist()
+        assert not bad, (s, bad)
+    got, glv, grv = outs[0].cpu().numpy(), lvs[0].cpu().numpy(), rvs[0].cpu().numpy()
+    occ_np = occ_buf.cpu().numpy()
+    for f in (0, 1, 17, 31):
+        conf = oracle.occlusion_heuristic(b["hints"][f])[1]
+        assert np.array_equal(conf, occ_np[f]), f
+        oracle.init_rand(11 + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], g_occ=conf)
+        assert np.array_equal(lo, glv[f]) and np.array_equal(ro, grv[f]), f
+        assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D, subpixel=True), got[f]), f
+
+
+def _small_batch(eng, B=8, H=135, W=240, D=192, seed=9):
+    b = synth.make_batch(B, H, W, D, 0.04, seed=seed)
+    return b, [_dev(eng, b[k]) for k in ("left", "right", "hints")]
+
+
+def test_forced_lockstep_timeout_is_reported_by_the_same_calls_sync():
+    """VPPX_V3_SPIN_LIMIT=1 makes every wave of the fused kernel give up at the first neighbour record that is not there
+    yet.  The synchronisation of that very call must report it; the next call runs the line-parallel layout and is
+    right; nothing is reported twice."""
+    import torch
+    from vppstereo_amd._lib import VppxError
+    D = 192
+    eng = _engine(VPPX_VERT=3, VPPX_V3_SPIN_LIMIT=1)
+    ref = _engine(VPPX_VERT=0)
+    b, args = _small_batch(eng)
+    want = ref.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
+    ref.synchronize()
+    eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
+    assert eng.uses_vert() == 3
+    with pytest.raises(VppxError, match="lost its lock step") as ei:
+        eng.synchronize()
+    assert ei.value.code == -8          # VPPX_E_HIP
+    assert eng.ctx.lockstep_failures == 1
+    eng.synchronize()                   # reported once
+    out = eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
+    eng.synchronize()
+    assert eng.uses_vert() == 0         # the context stays on the line-parallel kernel
+    assert torch.equal(out, want)
+    oracle.init_rand(3)
+    lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
+    assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, dmax=D), out[0].cpu().numpy())
+
+
+def test_forced_lockstep_timeout_is_seen_by_status_and_by_the_next_call():
+    """A caller that synchronises through torch asks vppx_status; one that does not ask at all gets the error from its
+    next call into the hot path (before anything is queued)."""
+    import torch
+    from vppstereo_amd._lib import VppxError
+    D = 192
+    ref = _engine(VPPX_VERT=0)
+    eng = _engine(VPPX_VERT=3, VPPX_V3_SPIN_LIMIT=1)
+    b, args = _small_batch(eng, seed=10)
+    want = ref.vpp_rsgm(*args, seed=4, rsgm_kw=dict(dmax=D))
+    ref.synchronize()
+    eng.status()                        # nothing has run: healthy
+    eng.vpp_rsgm(*args, seed=4, rsgm_kw=dict(dmax=D))
+    torch.cuda.synchronize()
+    with pytest.raises(VppxError, match="lost its lock step"):
+        eng.status()
+    eng.status()
+    eng2 = _engine(VPPX_VERT=3, VPPX_V3_SPIN_LIMIT=1)
+    eng2.vpp_rsgm(*args, seed=4, rsgm_kw=dict(dmax=D))
+    torch.cuda.synchronize()
+    with pytest.raises(VppxError, match="lost its lock step"):
+        eng2.occlusion_heuristic(args[2])
+    for e in (eng, eng2):
+        out = e.vpp_rsgm(*args, seed=4, rsgm_kw=dict(dmax=D))
+        e.synchronize()
+        assert e.uses_vert() == 0 and torch.equal(out, want)
+
+
+def test_forced_lockstep_timeout_host_entry_point_recovers_by_itself():
+    """vppx_rsgm_host is synchronous: it sees the mark of its own aggregation and repeats it on the line-parallel
+    kernel, so a host-pointer caller (the compute_rsgm drop-in) never receives void disparities."""
+    from vppstereo_amd import _lib
+    B, H, W, D = 4, 64, 160, 192
+    old = {k: os.environ.get(k) for k in ("VPPX_VERT", "VPPX_V3_SPIN_LIMIT")}
+    os.environ["VPPX_VERT"], os.environ["VPPX_V3_SPIN_LIMIT"] = "3", "1"
+    try:
+        ctx = _lib.Context()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    lib = _lib.load()
+    b = synth.make_batch(B, H, W, D, 0.05, seed=21)
+    lv, rv = np.empty_like(b["left"]), np.empty_like(b["right"])
+    for f in range(B):
+        oracle.init_rand(f)
+        lv[f], rv[f] = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
+    out = np.zeros((B, H, W), np.float32)
+    p = _lib.rsgm_params(dmax=D)
+    _lib.check(lib.vppx_rsgm_host(ctx.handle, C.byref(p), B, H, W, 3, _lib.np_ptr(b["left"]), _lib.np_ptr(lv), _lib.np_ptr(rv),
+                                  None, None, _lib.np_ptr(out)))
+    assert ctx.lockstep_failures == 1 and lib.vppx_uses_vert(ctx.handle) == 0
+    for f in range(B):
+        assert np.array_equal(oracle.compute_rsgm(b["left"][f], lv[f], rv[f], dmax=D), out[f]), f
+    ctx.status()
+
+
+def test_forced_lockstep_timeout_under_graph_replay():
+    """Graph mode: the captured graph holds the fused launch.  After a lost lock step the graph is dropped, the error is
+    returned (not swallowed by a silent eager retry), and later calls capture the line-parallel layout."""
+    import torch
+    from vppstereo_amd._lib import VppxError
+    D = 192
+    ref = _engine(VPPX_VERT=0)
+    eng = _engine(VPPX_VERT=3, VPPX_V3_SPIN_LIMIT=1)
+    b, args = _small_batch(eng, seed=12)
+    want = ref.vpp_rsgm(*args, seed=6, rsgm_kw=dict(dmax=D)).clone()
+    ref.synchronize()
+    out = torch.empty_like(want)
+    side = torch.cuda.Stream(device=eng.device)
+    with torch.cuda.stream(side):
+        eng.set_graph_mode(True)
+        seen = 0
+        for _ in range(6):
+            try:
+                eng.vpp_rsgm(*args, out=out, seed=6, rsgm_kw=dict(dmax=D))
+                eng.synchronize()
+            except VppxError as e:
+                assert "lost its lock step" in str(e)
+                seen += 1
+        assert seen == 1 and eng.ctx.lockstep_failures == 1
+        assert eng.uses_vert() == 0 and eng.graph_replays() > 0
+        assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("p1", [62, 231, 232, 20000, 70000])
+def test_large_p1_is_exact_on_both_layouts(p1):
+    """P1 far above P2: the byte-volume kernels clamp it (exact, see rsgm_launch_paths); the oracle saturates in u16."""
+    import torch
+    D = 192
+    fused, eight = _engine(VPPX_VERT=3), _engine(VPPX_VERT=0)
+    b, args = _small_batch(fused, B=8, H=40, W=112, seed=30)
+    kw = dict(dmax=D, p1=p1)
+    of = fused.vpp_rsgm(*args, seed=1, rsgm_kw=kw)
+    o8 = eight.vpp_rsgm(*args, seed=1, rsgm_kw=kw)
+    fused.synchronize()
+    eight.synchronize()
+    assert fused.uses_vert() == 3 and eight.uses_vert() == 0
+    assert torch.equal(of, o8)
+    o1 = eight.vpp_rsgm(*[a[:1].contiguous() for a in args], seed=1, rsgm_kw=kw)   # 16 lanes x 12 variant
+    eight.synchronize()
+    assert torch.equal(o1[0], o8[0])
+    oracle.init_rand(1)
+    lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
+    assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, dmax=D, p1=p1), of[0].cpu().numpy())
+
+
+def _torch_batches(eng, n, B=8, H=40, W=120, D=192):
+    out = []
+    for i in range(n):
+        b = synth.make_batch(B, H, W, D, 0.05, seed=70 + i)
+        out.append([_dev(eng, b[k]) for k in ("left", "right", "hints")])
+    return out
+
+
+def test_pipelining_is_safe_with_torch_produced_inputs_and_per_call_tensors():
+    """Cross-call pipelining without any promise from the caller: every call's inputs are produced by torch kernels
+    queued immediately before it, every input and output tensor is allocated per call and dropped right after (torch's
+    allocator hands the memory to the next iteration), junk is written into fresh allocations in between.  The front
+    stage must wait for the producers and must never write caller memory out of stream order."""
+    import torch
+    D = 192
+    ref, eng = _engine(), _engine()
+    eng.set_pipeline(True)
+    base = _torch_batches(eng, 3)
+    want, want_occ, want_lv = [], [], []
+    for i, (l, r, h) in enumerate(base):
+        occ = ref.occlusion_heuristic(h)
+        lv = torch.empty_like(l)
+        want.append(ref.vpp_rsgm(l, r, h, g_occ=occ, l_vpp=lv, seed=i, rsgm_kw=dict(dmax=D)).clone())
+        want_occ.append(occ.clone())
+        want_lv.append(lv)
+    ref.synchronize()
+    got = []
+    for rep in range(4):
+        for i, (bl, br, bh) in enumerate(base):
+            l = bl.clone()                                  # producers: torch kernels on the current stream, just before the call
+            r = torch.flip(torch.flip(br, [1]), [1])
+            h = bh * 1.0
+            occ = torch.empty(bh.shape, dtype=torch.uint8, device=eng.device)
+            lv = torch.empty_like(l)
+            out = eng.vpp_rsgm(l, r, h, g_occ="occlusion_heuristic", occ_out=occ, l_vpp=lv, seed=i, rsgm_kw=dict(dmax=D))
+            got.append((i, out.double().sum(), occ.sum(), lv.sum(dtype=torch.int64), out))   # consumers right behind it
+            del l, r, h, occ, lv
+            junk = [torch.empty(bl.shape, dtype=torch.uint8, device=eng.device).fill_(7 + rep) for _ in range(3)]
+            del junk
+    eng.synchronize()
+    for i, s_out, s_occ, s_lv, out in got:
+        assert torch.equal(out, want[i]), i
+        assert float(s_out) == float(want[i].double().sum()), i
+        assert int(s_occ) == int(want_occ[i].sum()) and int(s_lv) == int(want_lv[i].sum(dtype=torch.int64)), i
+
+
+def test_pipelining_with_an_inputs_ready_event_from_a_loader_stream():
+    """The overlapped form: inputs are produced on a second ("loader") stream and the caller passes the event recorded
+    there; the front stage waits for that event only.  The launch stream never waits for the loader explicitly: the
+    library's own ordering (front stage -> aggregation) must cover it."""
+    import torch
+    D = 192
+    ref, eng = _engine(), _engine()
+    eng.set_pipeline(True)
+    base = _torch_batches(eng, 3, B=12, H=33, W=70)
+    want = []
+    for i, (l, r, h) in enumerate(base):
+        occ = ref.occlusion_heuristic(h)
+        want.append(ref.vpp_rsgm(l, r, h, g_occ=occ, seed=i, rsgm_kw=dict(dmax=D)).clone())
+    ref.synchronize()
+    loader = torch.cuda.Stream(device=eng.device)
+    keep, got = [], []
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for i, (bl, br, bh) in enumerate(base):
+            with torch.cuda.stream(loader):
+                l, r, h = bl.clone(), br.clone(), bh.clone()
+                for _ in range(3):
+                    h = h * 1.0                              # a loader with some latency
+                ev = torch.cuda.Event()
+                ev.record(loader)
+            out = eng.vpp_rsgm(l, r, h, g_occ="occlusion_heuristic", seed=i, rsgm_kw=dict(dmax=D), inputs_ready=ev)
+            got.append((i, out))
+            keep.append((l, r, h, ev))                       # loader-stream tensors stay alive until the end
+    eng.synchronize()
+    for i, out in got:
+        assert torch.equal(out, want[i]), i

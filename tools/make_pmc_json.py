@@ -23,6 +23,10 @@ def passes(tag, name):
         for r in csv.DictReader(open(f)):
             k = re.split(r"[<(]", re.sub(r"^void ", "", r["Kernel_Name"]))[0]
             acc[k][r["Counter_Name"]].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
+            try:
+                acc[k]["_dur_ns"].append((int(r.get("Grid_Size", 0) or 0), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
+            except (KeyError, ValueError):
+                pass
     return acc
 
 
@@ -47,7 +51,13 @@ def main():
         if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
             d["hbm_GB_per_launch"] = round((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1e3 / 1e9, 3)
         for c, v in sq.get(k, {}).items():
-            d[c], _ = big_avg(v)
+            if c == "_dur_ns":
+                d["kernel_ms_in_SQ_pass"] = big_avg(v)[0] / 1e6
+            else:
+                d[c], _ = big_avg(v)
+        if d.get("GRBM_GUI_ACTIVE") and d.get("kernel_ms_in_SQ_pass"):
+            # GRBM_GUI_ACTIVE counts shader-clock cycles per XCD, summed over the 8 XCDs
+            d["sclk_mhz_profiled"] = round(d["GRBM_GUI_ACTIVE"] / 8.0 / (d["kernel_ms_in_SQ_pass"] * 1e-3) / 1e6, 1)
         if "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"] > 0:
             for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
                 if c in d:
@@ -57,7 +67,13 @@ def main():
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
     except Exception:
         commit = None
-    doc = {"note": "rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ set, each its own run) of "
+    # real HBM traffic of one step: every kernel's per-launch bytes x its full-batch launches per step (the sum/WTA kernel
+    # runs once per step)
+    per_step = None
+    ref_n = kern.get("sum_wta_lr_kernel", {}).get("launches")
+    if ref_n:
+        per_step = round(sum(v["hbm_GB_per_launch"] * v.get("launches", 0) / ref_n for v in kern.values() if "hbm_GB_per_launch" in v), 3)
+    doc = {"hbm_GB_per_step": per_step, "note": "rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ set, each its own run) of "
                    "`python3 bench.py` by tools/prof_round.sh; per-launch averages over the full-batch launches, summed over the "
                    "chip.  hbm_GB_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB.  SQ_* cycle counters are quad-cycles summed over waves.",
            "commit": commit, "kernel_source_sha": bench.kernel_source_sha(), "batch": batch, "H": bench.H, "W": bench.W, "D": bench.D,

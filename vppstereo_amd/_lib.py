@@ -22,12 +22,12 @@ ERR_NAMES = {
 
 # every symbol include/vppx.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "vppx_version", "vppx_last_error", "vppx_vpp_params_default", "vppx_rsgm_params_default", "vppx_create",
-    "vppx_destroy", "vppx_set_stream", "vppx_set_stream_legacy", "vppx_set_pipeline", "vppx_synchronize", "vppx_workspace_bytes", "vppx_device_name", "vppx_srand",
+    "vppx_version", "vppx_last_error", "vppx_vpp_params_default", "vppx_rsgm_params_default", "vppx_occ_params_default", "vppx_create",
+    "vppx_destroy", "vppx_set_stream", "vppx_set_stream_legacy", "vppx_set_pipeline", "vppx_synchronize", "vppx_status", "vppx_lockstep_failures", "vppx_workspace_bytes", "vppx_device_name", "vppx_srand",
     "vppx_rand_stream", "vppx_rand_state", "vppx_rand_advance", "vppx_virtual_projection_scan_rnd", "vppx_virtual_projection_scan_max_dist", "vppx_vpp_host",
     "vppx_vpp_dev", "vppx_vpp_last_draws", "vppx_census5x5", "vppx_cost_census5x5_xyd", "vppx_aggregate", "vppx_aggregate_img", "vppx_match_wta",
     "vppx_match_wta_right", "vppx_subpixel_refine", "vppx_median3x3", "vppx_rsgm_host", "vppx_rsgm_dev",
-    "vppx_vpp_rsgm_dev", "vppx_u8_to_nchw_dev", "vppx_psmnet_cost_volume_dev", "vppx_raft_corr_modulate_dev", "vppx_kitti_disp_decode_dev", "vppx_png_decode_dev", "vppx_pfm_decode_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_set_graph_mode", "vppx_graph_replays", "vppx_time_aggregate", "vppx_agg_kernel_ms", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert",
+    "vppx_vpp_rsgm_dev", "vppx_occ_vpp_rsgm_dev", "vppx_inputs_ready_event", "vppx_u8_to_nchw_dev", "vppx_psmnet_cost_volume_dev", "vppx_raft_corr_modulate_dev", "vppx_kitti_disp_decode_dev", "vppx_png_decode_dev", "vppx_pfm_decode_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_set_graph_mode", "vppx_graph_replays", "vppx_time_aggregate", "vppx_agg_kernel_ms", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert",
     "vppx_enable_stage_timing", "vppx_get_stage_ms", "vppx_stage_name",
 ]
 
@@ -48,6 +48,11 @@ class VppxRsgmParams(C.Structure):
         ("dmax", C.c_int32), ("p1", C.c_int32), ("p2min", C.c_int32), ("alpha", C.c_float), ("gamma", C.c_int32),
         ("uniqueness", C.c_float), ("subpixel", C.c_int32), ("reserved0", C.c_int32),
     ]
+
+
+class VppxOccParams(C.Structure):
+    _fields_ = [("rx", C.c_int32), ("ry", C.c_int32), ("l", C.c_double), ("g", C.c_double), ("th_conf", C.c_double),
+                ("th_filter", C.c_double)]
 
 
 class VppxError(Exception):
@@ -97,6 +102,9 @@ def load():
         lib.vppx_set_stream_legacy.argtypes = [vp]
         lib.vppx_set_pipeline.argtypes = [vp, C.c_int]
         lib.vppx_synchronize.argtypes = [vp]
+        lib.vppx_status.argtypes = [vp]
+        lib.vppx_lockstep_failures.argtypes = [vp]
+        lib.vppx_lockstep_failures.restype = C.c_long
         lib.vppx_srand.argtypes = [vp, C.c_uint32]
         lib.vppx_rand_state.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         lib.vppx_rand_advance.argtypes = [vp, C.c_uint64]
@@ -123,6 +131,11 @@ def load():
         lib.vppx_rsgm_host.argtypes = [vp, pr, i, i, i, i, vp, vp, vp, vp, vp, vp]
         lib.vppx_rsgm_dev.argtypes = [vp, pr, i, i, i, i, vp, vp, vp, vp, vp, vp]
         lib.vppx_vpp_rsgm_dev.argtypes = [vp, pv, pr, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
+        po = C.POINTER(VppxOccParams)
+        lib.vppx_occ_params_default.argtypes = [po]
+        lib.vppx_occ_params_default.restype = None
+        lib.vppx_occ_vpp_rsgm_dev.argtypes = [vp, po, pv, pr, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
+        lib.vppx_inputs_ready_event.argtypes = [vp, vp]
         lib.vppx_u8_to_nchw_dev.argtypes = [vp, i, i, i, i, i, vp, vp, i]
         lib.vppx_psmnet_cost_volume_dev.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
         lib.vppx_raft_corr_modulate_dev.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i]
@@ -192,7 +205,16 @@ class Context:
         check(self._lib.vppx_set_stream(self._h, None))
 
     def synchronize(self):
+        """Wait for the context's stream; raises VppxError when a fused aggregation launch lost its lock step."""
         check(self._lib.vppx_synchronize(self._h))
+
+    def status(self):
+        """Non-blocking health check (vppx_status): raises VppxError for a lost lock step seen so far."""
+        check(self._lib.vppx_status(self._h))
+
+    @property
+    def lockstep_failures(self):
+        return int(self._lib.vppx_lockstep_failures(self._h))
 
     @property
     def device_name(self):
@@ -238,6 +260,12 @@ def _fill(p, kw):
 def vpp_params(**kw):
     p = VppxVppParams()
     load().vppx_vpp_params_default(C.byref(p))
+    return _fill(p, kw)
+
+
+def occ_params(**kw):
+    p = VppxOccParams()
+    load().vppx_occ_params_default(C.byref(p))
     return _fill(p, kw)
 
 

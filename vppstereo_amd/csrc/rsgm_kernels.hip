@@ -849,6 +849,11 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
     if ((size_t)Hp * Wp * D >= ((size_t)1 << 32)) { vppx_set_error("frame volume too large"); return VPPX_E_UNSUPPORTED; }
     const bool from_dsi = dsi != nullptr;
     if (from_dsi || D % 64 != 0) elem_bytes = 2; // those variants always write u16 volumes
+    // Byte volumes run the small-value update (plain 32-bit adds on packed pairs, f16-pattern three-way minimum): its
+    // operands must stay far below 0x7C00, which an unclamped P1 would break (0x3FFF + P1).  Clamping P1 to any value
+    // >= P2max is exact: L(d+-1) + P1 >= min_k L(k) + P1 >= min_k L(k) + P2, so the P1 terms can never win the minimum
+    // once P1 >= P2, and byte volumes imply P2max <= 231.
+    if (elem_bytes == 1 && p1 > 231) a.p1 = 231;
     // lanes per pixel x disparities per lane: few lanes per pixel amortise the per-step overhead
     // (min reduction, P2 lookup, addressing) over more disparities
     static int gw_override = -1;
@@ -1188,12 +1193,16 @@ struct Vert3Args {
     const u16 *p2lut;
     u8 *sv;     // [2 passes][B][Hp][Wp][D]
     u32 *xbuf;  // [2B groups][nwv][V3_RING rows][2 directions][8 lanes][XW] edge records
-    unsigned *err; // host-visible word, set when a wave gave up waiting for a neighbour (results void)
+    unsigned *err; // host-visible word, set (to the launch serial) when a wave gave up waiting for a neighbour (results void)
     int B, Hp, Wp, p1;
     int nwv, nbg; // waves / blocks per group
     size_t vol_elems;
+    // bounds of one wait for a neighbour's record: wall-clock ticks (s_memrealtime, constant rate: the bound that
+    // counts) and, for tests, a number of polls (0 = unbounded: VPPX_V3_SPIN_LIMIT)
+    long long timeout_ticks;
+    unsigned spin_limit;
+    unsigned serial; // launch serial written to *err (never 0)
 };
-#define V3_SPIN_LIMIT (1 << 16)
 // Rows of edge records kept per wave.  A wave may write the record of row t+1 while a neighbour is still reading the
 // one of row t-1 (the NW record of a row is published before the NE record of the row before has been consumed), so
 // the slot reused must be at least three rows old: a ring of four.
@@ -1222,18 +1231,32 @@ __device__ __forceinline__ void v3_edges_issue(__amdgpu_buffer_rsrc_t xr, int of
     r.m = __builtin_amdgcn_raw_buffer_load_b32(xr, off + 4 * NP, 0, V3_SC1);
 }
 template <int NP>
-__device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int off, bool want, u32 T, V3Edge<NP> &r, bool &dead)
+__device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int off, bool want, u32 T, V3Edge<NP> &r, bool &dead,
+                                                  long long timeout_ticks, unsigned spin_limit)
 {
-    int spins = dead ? V3_SPIN_LIMIT - 2 : 0; // a wave that gave up once does not wait again (results are void anyway)
+    // The wait is bounded in TIME (s_memrealtime runs at a constant rate whatever the shader clock and the L2 latency
+    // are; looked at every 32nd poll) and, when a test asks for it, in polls.  A wave that gave up once does not wait
+    // again: its results are void anyway, and its neighbours must not inherit a full timeout per row.
+    unsigned spins = 0;
+    long long t0 = 0;
     for (;;) {
         u32 bad = r.m ^ T;
 #pragma unroll
         for (int k = 0; k < NP / 4; k++) bad |= (r.p[k].x ^ T) | (r.p[k].w ^ T);
         const bool ok = !want || (bad & V3_TAGMASK) == 0;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-        if (++spins >= V3_SPIN_LIMIT) {
+        ++spins;
+        if (dead || (spin_limit && spins >= spin_limit)) {
             dead = true;
             break;
+        }
+        if ((spins & 31u) == 1u) {
+            const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+            if (spins == 1u) t0 = now;
+            else if (now - t0 > timeout_ticks) {
+                dead = true;
+                break;
+            }
         }
         __builtin_amdgcn_s_sleep(1);
         v3_edges_issue<NP>(xr, off, r);
@@ -1366,7 +1389,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         v3_edges_issue<NP>(xrsrc, eoff, er);
         // ---- straight path: needs nobody else's state
         sgm_update_split<NP, 8>(L0, C, P1pk, P2a, mn0, first, last);
-        v3_edges_complete<NP>(xrsrc, eoff, want, Tin, er, dead);
+        v3_edges_complete<NP>(xrsrc, eoff, want, Tin, er, dead, a.timeout_ticks, a.spin_limit);
         __builtin_amdgcn_s_setprio(2); // from here to the second publish the neighbours wait for this wave
         {
             u32 e[NP + 1];
@@ -1461,7 +1484,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         prevI = I;
     }
     store_pend();
-    if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The lock-step hand-off goes through ONE L2: all blocks of a (frame, pass) group must run on the same XCD, which the
@@ -1476,6 +1499,20 @@ __global__ void __launch_bounds__(64) xcc_probe_kernel(u32 *out)
         out[blockIdx.x] = xcc & 0xFu;
     }
 }
+template <int DPL>
+static int v3_blocks_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)sgm_vert3_kernel<DPL>, 256, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    return n;
+}
+
+// Fills ctx->v3: how this device places consecutive block ids (one XCD id per blockIdx & 7, eight different ones), how
+// many CUs one XCD has and how many blocks of each fused kernel fit a CU -- asked of the runtime for THIS build of the
+// kernels on THIS device (VGPR counts move with the compiler; SKUs, partitions and CU masks move the CU count).
 int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *ok)
 {
     u32 h[256];
@@ -1483,24 +1520,52 @@ int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *o
     VPPX_CHECK_LAUNCH();
     VPPX_HIP(hipMemcpyAsync(h, scratch_dev, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     VPPX_HIP(hipStreamSynchronize(ctx->stream));
-    *ok = true;
+    bool pattern = true;
     for (int i = 8; i < 256; i++)
-        if (h[i] != h[i & 7]) *ok = false;
+        if (h[i] != h[i & 7]) pattern = false;
+    u32 seen = 0;
+    for (int i = 0; i < 8; i++) seen |= 1u << (h[i] & 15u);
+    const int nxcd = __builtin_popcount(seen);
+    int ncu = 0;
+    VPPX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) {
+        (void)hipGetLastError();
+        khz = 100000; // s_memrealtime of gfx9: 100 MHz
+    }
+    ctx->v3.nxcd = nxcd;
+    ctx->v3.cus_per_xcd = nxcd > 0 ? ncu / nxcd : 0;
+    ctx->v3.blocks_per_cu[0] = v3_blocks_per_cu<8>();
+    ctx->v3.blocks_per_cu[1] = v3_blocks_per_cu<16>();
+    ctx->v3.blocks_per_cu[2] = v3_blocks_per_cu<24>();
+    ctx->v3.blocks_per_cu[3] = v3_blocks_per_cu<32>();
+    ctx->v3.wall_khz = khz;
+    // The kernel decodes (group, block) from blockIdx assuming 8 XCDs that take block ids round-robin.  A single-XCD
+    // partition (CPX) passes the pattern test trivially, but there the 8 interleaved groups would have to share the one
+    // XCD: no fused layout on anything but the 8-XCD placement the kernel was written for.
+    ctx->v3.ok = pattern && nxcd == 8 && ctx->v3.cus_per_xcd > 0;
+    *ok = ctx->v3.ok;
     return 0;
 }
 
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
 {
-    // edge values and their packed minimum must stay below 1024 (tag bits), the three-path sum below 256
-    // (record offsets are 32-bit byte offsets into one buffer: keep it below 1 GiB)
-    // All blocks of a (frame, pass) group must be resident together, with room to spare for the blocks of the next group
-    // that arrive early: at most 3/4 of the block slots of one XCD (32 CUs x 8 / 5 / 4 / 3 blocks for D = 64 .. 256:
-    // 56 / 84 / 116 / 142 VGPRs).  Wider frames take the 8-path layout.
-    const int blocks_per_cu = D == 64 ? 8 : (D == 128 ? 5 : (D == 192 ? 4 : 3));
-    const int nbg = (Wp / 8 + 3) / 4;
+    // shape conditions only (rsgm_vert3_fits has the residency condition): edge values and their packed minimum must
+    // stay below 1024 (tag bits), the three-path sum below 256; record offsets are 32-bit byte offsets into one buffer
+    // (kept below 1 GiB)
     return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095 &&
-           nbg <= 32 * blocks_per_cu * 3 / 4 &&
            (size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * 32) * sizeof(u32) < ((size_t)1 << 30);
+}
+
+// All blocks of a (frame, pass) group must be resident together, with room to spare for the blocks of the next group
+// that arrive early: at most 3/4 of the block slots of one XCD, counted with what the runtime says about this device
+// and this build (after rsgm_vert3_probe).  Wider frames take the 8-path layout.
+bool rsgm_vert3_fits(const vppx_ctx *ctx, int Wp, int D)
+{
+    if (!ctx->v3.ok) return false;
+    const int k = D == 64 ? 0 : (D == 128 ? 1 : (D == 192 ? 2 : 3));
+    const int nbg = (Wp / 8 + 3) / 4;
+    return nbg <= ctx->v3.cus_per_xcd * ctx->v3.blocks_per_cu[k] * 3 / 4;
 }
 static int v3_xw(int D) { return D == 256 ? V3Rec<16>::XW : 16; }
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D)
@@ -1513,10 +1578,15 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
 {
     Vert3Args a;
     a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.xbuf = xbuf; a.err = err;
-    a.B = B; a.Hp = Hp; a.Wp = Wp; a.p1 = p1;
+    a.B = B; a.Hp = Hp; a.Wp = Wp;
+    a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (see rsgm_launch_paths); keeps the small-value update in range
     a.nwv = Wp / 8;
     a.nbg = (a.nwv + 3) / 4;
     a.vol_elems = (size_t)B * Hp * Wp * D;
+    a.timeout_ticks = (long long)ctx->v3.timeout_ms * (long long)(ctx->v3.wall_khz > 0 ? ctx->v3.wall_khz : 100000);
+    a.spin_limit = ctx->v3.spin_limit;
+    a.serial = ++ctx->v3.serial;
+    if (a.serial == 0) a.serial = ++ctx->v3.serial;
     VPPX_HIP(hipMemsetAsync(xbuf, 0, rsgm_vert3_xbuf_bytes(B, Wp, D), stream)); // no record of an earlier launch may match
     const dim3 grid((unsigned)(2 * B * a.nbg));
     if (D == 64) sgm_vert3_kernel<8><<<grid, 256, 0, stream>>>(a);
@@ -1524,7 +1594,6 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     else if (D == 192) sgm_vert3_kernel<24><<<grid, 256, 0, stream>>>(a);
     else sgm_vert3_kernel<32><<<grid, 256, 0, stream>>>(a);
     VPPX_CHECK_LAUNCH();
-    (void)ctx;
     return 0;
 }
 

@@ -69,6 +69,17 @@ extern "C" void vppx_vpp_params_default(VppxVppParams *p)
     p->bilateral_th = 0.001;
 }
 
+extern "C" void vppx_occ_params_default(VppxOccParams *p) // filter.py:246
+{
+    memset(p, 0, sizeof(*p));
+    p->rx = 9;
+    p->ry = 7;
+    p->l = 2.0;
+    p->g = 0.4375;
+    p->th_conf = 1.0;
+    p->th_filter = 0.1;
+}
+
 extern "C" void vppx_rsgm_params_default(VppxRsgmParams *p)
 {
     memset(p, 0, sizeof(*p));
@@ -161,6 +172,12 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (e && atoi(e) > 0) ctx->graph_mode = true;
         e = getenv("VPPX_SUBSTREAMS");
         if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+        // bounds of one neighbour wait in the fused aggregation kernel: milliseconds of wall clock (the bound that counts)
+        // and, for tests that must see the give-up path, a number of polls (1 = give up at the first record not there yet)
+        e = getenv("VPPX_V3_TIMEOUT_MS");
+        if (e && atoi(e) > 0) ctx->v3.timeout_ms = atoi(e);
+        e = getenv("VPPX_V3_SPIN_LIMIT");
+        if (e && atoi(e) > 0) ctx->v3.spin_limit = (unsigned)atoi(e);
     }
     *out = ctx;
     return 0;
@@ -188,6 +205,7 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
     if (ctx->ev_agg_done) (void)hipEventDestroy(ctx->ev_agg_done);
     if (ctx->ev_front_done) (void)hipEventDestroy(ctx->ev_front_done);
+    if (ctx->ev_inputs_auto) (void)hipEventDestroy(ctx->ev_inputs_auto);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -253,12 +271,47 @@ extern "C" int vppx_set_stream_legacy(vppx_ctx *ctx)
     return 0;
 }
 
+// The fused aggregation kernel (sgm_vert3_kernel) reports a lost lock step -- a wave that waited longer than the bound
+// for its neighbour's record -- through a pinned host word.  Whoever looks at it first reports it: vppx_status,
+// vppx_synchronize, the host-pointer entry points after their own synchronisation, and the next call of the hot path.
+// The context then stays on the line-parallel kernel (vert3_broken) and a captured graph holding the launch is dropped.
+static int lockstep_check(vppx_ctx *ctx)
+{
+    if (!ctx->vert3_err || !ctx->vert3_err[0]) return 0;
+    const unsigned serial = ctx->vert3_err[0];
+    ctx->vert3_err[0] = 0;
+    ctx->vert3_broken = true;
+    ctx->lockstep_failures++;
+    if (ctx->gexec) {
+        (void)hipGraphExecDestroy(ctx->gexec);
+        ctx->gexec = nullptr;
+        ctx->have_gkey = false;
+    }
+    ctx->have_lastkey = false;
+    vppx_set_error("fused aggregation launch #%u lost its lock step (a wave waited longer than %d ms%s for its neighbour): the "
+                   "disparities of that call are void, and so are those of fused calls queued behind it (last launch: #%u); "
+                   "the context uses the line-parallel aggregation kernel from now on",
+                   serial, ctx->v3.timeout_ms, ctx->v3.spin_limit ? " / VPPX_V3_SPIN_LIMIT polls" : "", ctx->v3.serial);
+    return VPPX_E_HIP;
+}
+
 extern "C" int vppx_synchronize(vppx_ctx *ctx)
 {
     VPPX_ENTER(ctx);
     VPPX_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return lockstep_check(ctx);
 }
+
+// Non-blocking: has any fused aggregation launch that has finished so far lost its lock step?  (After a synchronisation
+// of the launch stream -- by whatever means, e.g. torch.cuda.synchronize -- the answer covers every call made so far.)
+extern "C" int vppx_status(vppx_ctx *ctx)
+{
+    VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
+    return lockstep_check(ctx);
+}
+
+extern "C" long vppx_lockstep_failures(vppx_ctx *ctx) { return ctx ? ctx->lockstep_failures : 0; }
 
 extern "C" size_t vppx_workspace_bytes(const vppx_ctx *ctx)
 {
@@ -274,7 +327,8 @@ extern "C" const char *vppx_device_name(const vppx_ctx *ctx) { return ctx ? ctx-
 // stage timing
 // ---------------------------------------------------------------------------------------
 static const char *k_stage_names[ST_COUNT] = {"vpp_compact", "vpp_rand", "vpp_apply", "pad_gray", "census",
-                                              "aggregate_8paths", "sum_wta_left", "wta_right", "median_interp", "post"};
+                                              "aggregate_8paths", "sum_wta_left", "wta_right", "median_interp", "post",
+                                              "occlusion_heuristic"};
 
 extern "C" const char *vppx_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? k_stage_names[i] : ""; }
 
@@ -396,14 +450,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     const size_t npp = (size_t)g.B * g.Hp * g.Wp;
     const size_t ncell = npp * g.D;
     int nvol;
-    if (ctx->vert3_err && ctx->vert3_err[0]) {
-        // a wave of an earlier fused launch gave up waiting for its neighbour (bounded polls): that call's disparities
-        // are void.  Say so once, and keep this context on the line-parallel kernel from now on.
-        ctx->vert3_err[0] = 0;
-        ctx->vert3_broken = true;
-        vppx_set_error("an earlier fused aggregation launch lost its lock step: its results are void; the context now uses the line-parallel kernel");
-        return VPPX_E_HIP;
-    }
+    if ((rc = lockstep_check(ctx))) return rc; // an earlier fused launch lost its lock step: say so before queueing more
     if (hints && validhints) {
         // --guided (rsgm.py:265-268): like the reference, materialise the cost volume, re-weight the
         // hint pixels' rows, aggregate from it (costs reach 240: u16 path volumes)
@@ -426,16 +473,17 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     // B=32 13.3 / 11.7); a context whose fused launch once lost its lock step never uses it again.
     bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
     if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192)))) {
-        // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes?
+        // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes
+        // (8 XCDs, round-robin), and how many blocks of this build of the kernel does one XCD hold?
         u32 *probe;
         bool ok = false;
         if ((rc = ws_get(ctx, WS_VMIN, (size_t)512, (u16 **)&probe))) return rc;
         if ((rc = rsgm_vert3_probe(ctx, probe, &ok))) return rc;
         ctx->vert3_probed = true;
         if (!ok) ctx->vert3_broken = true;
-        v3_ok = ok;
     }
-    if (ctx->capturing && !ctx->vert3_probed) v3_ok = false; // (a first call inside a graph capture takes the 8-path layout)
+    if (!ctx->vert3_probed) v3_ok = false; // (e.g. a first call inside a graph capture takes the 8-path layout)
+    v3_ok = v3_ok && !ctx->vert3_broken && rsgm_vert3_fits(ctx, g.Wp, g.D); // a whole group + early arrivals resident per XCD
     // (measured at B=32, 8-path / fused ms per step: D=64 7.5 / 7.5, D=128 10.6 / 9.2, D=192 13.3 / 11.7; 1536x2048x256 at
     // B=8 28.1 / 28.9: the default takes the fused layout for D = 128 and 192)
     const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192)));
@@ -535,21 +583,33 @@ static bool pipeline_applies(const vppx_ctx *ctx)
 {
     return ctx->pipeline && !ctx->capturing && !ctx->stage_timing && !ctx->is_child && !ctx->graph_mode && ctx->nsub <= 1;
 }
-// From here on ctx->stream is the front stream.  It waits for the previous pipelined call's aggregation (the last
-// reader of the census / gray / pattern buffers the front stage rewrites); the first pipelined call waits for
-// everything queued on the launch stream so far.
+// From here on ctx->stream is the front stream.  It waits for (1) the previous pipelined call's aggregation, the last
+// reader of the census / gray / pattern buffers the front stage rewrites (the first pipelined call waits for everything
+// queued on the launch stream so far), and (2) the inputs: the caller's inputs-ready event when one was given for this
+// call, else an event recorded on the launch stream right now, i.e. everything the caller queued before the call.
 static int front_begin(vppx_ctx *ctx)
 {
     if (!ctx->stream_front) {
         VPPX_HIP(hipStreamCreateWithFlags(&ctx->stream_front, hipStreamNonBlocking));
         VPPX_HIP(hipEventCreateWithFlags(&ctx->ev_agg_done, hipEventDisableTiming));
         VPPX_HIP(hipEventCreateWithFlags(&ctx->ev_front_done, hipEventDisableTiming));
+        VPPX_HIP(hipEventCreateWithFlags(&ctx->ev_inputs_auto, hipEventDisableTiming));
     }
     if (!ctx->have_agg_done) {
         VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
         ctx->have_agg_done = true;
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream_front, ctx->ev_agg_done, 0)); // covers the inputs as well
+        if (ctx->inputs_ev) VPPX_HIP(hipStreamWaitEvent(ctx->stream_front, (hipEvent_t)ctx->inputs_ev, 0));
+    } else {
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream_front, ctx->ev_agg_done, 0));
+        if (ctx->inputs_ev) {
+            VPPX_HIP(hipStreamWaitEvent(ctx->stream_front, (hipEvent_t)ctx->inputs_ev, 0));
+        } else {
+            VPPX_HIP(hipEventRecord(ctx->ev_inputs_auto, ctx->stream));
+            VPPX_HIP(hipStreamWaitEvent(ctx->stream_front, ctx->ev_inputs_auto, 0));
+        }
     }
-    VPPX_HIP(hipStreamWaitEvent(ctx->stream_front, ctx->ev_agg_done, 0));
+    ctx->inputs_ev = nullptr;
     ctx->main_saved = ctx->stream;
     ctx->stream = ctx->stream_front;
     ctx->front_active = true;
@@ -565,6 +625,11 @@ static int front_end(vppx_ctx *ctx)
     ctx->front_active = false;
     VPPX_HIP(hipEventRecord(ctx->ev_front_done, front));
     VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_front_done, 0));
+    // what the caller wanted of the front stage's results, delivered in launch-stream order (and before this call's
+    // aggregation, whose completion releases the library-owned buffers to the next front stage)
+    for (int i = 0; i < ctx->n_pipe_copy; i++)
+        VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->n_pipe_copy = 0;
     return 0;
 }
 struct FrontGuard { // error paths: never leave the context on the front stream
@@ -576,6 +641,7 @@ struct FrontGuard { // error paths: never leave the context on the front stream
             ctx->front_active = false;
         }
         ctx->pipe_call = false;
+        ctx->n_pipe_copy = 0;
     }
 };
 
@@ -678,6 +744,7 @@ extern "C" int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int 
 {
     int rc;
     VPPX_ENTER(ctx);
+    if ((rc = lockstep_check(ctx))) return rc;
     if (!p || !left || !left_vpp || !right_vpp || !disp_out) { vppx_set_error("vppx_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_frames(B, H, W, C))) return rc;
     if ((rc = check_rsgm_params(*p))) return rc;
@@ -707,9 +774,14 @@ extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int
         if ((rc = upload(ctx, WS_STAGE_E, hints, (size_t)B * H * W * sizeof(float), &dh))) return rc;
         if ((rc = upload(ctx, WS_STAGE_F, validhints, (size_t)B * H * W * sizeof(float), &dv))) return rc;
     }
-    if ((rc = vppx_rsgm_dev(ctx, p, B, H, W, C, (const u8 *)dl, (const u8 *)dlv, (const u8 *)drv, (const float *)dh, (const float *)dv, (float *)dout))) return rc;
-    if ((rc = download(ctx, disp_out, dout, (size_t)B * H * W * sizeof(float)))) return rc;
-    VPPX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int attempt = 0;; attempt++) {
+        if ((rc = vppx_rsgm_dev(ctx, p, B, H, W, C, (const u8 *)dl, (const u8 *)dlv, (const u8 *)drv, (const float *)dh, (const float *)dv, (float *)dout))) return rc;
+        if ((rc = download(ctx, disp_out, dout, (size_t)B * H * W * sizeof(float)))) return rc;
+        VPPX_HIP(hipStreamSynchronize(ctx->stream));
+        // a synchronous entry point knows whether ITS aggregation lost the lock step: run it again on the line-parallel
+        // kernel (the context has just moved there) instead of returning void disparities
+        if (lockstep_check(ctx) == 0 || attempt > 0) break;
+    }
     return 0;
 }
 
@@ -871,20 +943,41 @@ extern "C" int vppx_rand_stream(vppx_ctx *ctx, uint32_t seed, uint64_t offset, i
 // ---------------------------------------------------------------------------------------
 // fused hot path (test.py:158-225): VPP -> rSGM, batched, device resident
 // ---------------------------------------------------------------------------------------
-static int vpp_rsgm_one(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W, int C,
-                        const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ, uint8_t *l_vpp,
-                        uint8_t *r_vpp, float *disp_out)
+static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
+                        int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                        uint8_t *conf_out, uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
 {
     int rc;
-    const size_t nb = (size_t)B * H * W * C;
-    if (!l_vpp && (rc = ws_get(ctx, WS_VPP_L, nb, &l_vpp))) return rc;
-    if (!r_vpp && (rc = ws_get(ctx, WS_VPP_R, nb, &r_vpp))) return rc;
+    const size_t nb = (size_t)B * H * W * C, np = (size_t)B * H * W;
+    const bool piped = pipeline_applies(ctx);
+    // A pipelined front stage writes library-owned buffers only; the caller's copies are made on the launch stream
+    // (front_end).  One buffer each is enough: every reader of call k's front-stage results -- its own front stage, the
+    // copies, its aggregation -- is ordered before the event that lets the front stage of call k+1 start.
+    u8 *l_user = l_vpp, *r_user = r_vpp, *conf_user = conf_out;
+    if ((piped || !l_vpp) && (rc = ws_get(ctx, WS_VPP_L, nb, &l_vpp))) return rc;
+    if ((piped || !r_vpp) && (rc = ws_get(ctx, WS_VPP_R, nb, &r_vpp))) return rc;
+    float *omap = nullptr;
+    u8 *conf_scr = nullptr, *conf = conf_out;
+    if (op) {
+        if ((rc = ws_get(ctx, WS_OCC_OMAP, np, &omap))) return rc;
+        if ((rc = ws_get(ctx, WS_OCC_CONF, np, &conf_scr))) return rc;
+        if ((piped || !conf_out) && (rc = ws_get(ctx, WS_OCC_OUT, np, &conf))) return rc;
+    }
     FrontGuard guard{ctx};
-    if (pipeline_applies(ctx)) {
+    ctx->n_pipe_copy = 0;
+    if (piped) {
         ctx->pipe_call = true;
         if ((rc = front_begin(ctx))) return rc;
+        if (op && conf_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {conf_user, conf, np};
+        if (l_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {l_user, l_vpp, nb};
+        if (r_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {r_user, r_vpp, nb};
     }
     stage_begin(ctx);
+    if (op) { // test.py:154: g_occ = occlusion_heuristic(hints)[1]
+        if ((rc = occ_launch(ctx, B, H, W, g, op->rx, op->ry, op->l, op->g, op->th_conf, op->th_filter, omap, conf_scr, conf))) return rc;
+        stage_mark(ctx, ST_OCC);
+        g_occ = conf;
+    }
     // vpp() works on copies (np.copy, vpp_standalone.py:397)
     VPPX_HIP(hipMemcpyAsync(l_vpp, left, nb, hipMemcpyDeviceToDevice, ctx->stream));
     VPPX_HIP(hipMemcpyAsync(r_vpp, right, nb, hipMemcpyDeviceToDevice, ctx->stream));
@@ -902,17 +995,55 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmPa
     return rsgm_core(ctx, *rp, rg, left, l_vpp, r_vpp, disp_out);
 }
 
+static int vpp_rsgm_entry(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
+                          int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                          uint8_t *conf_out, uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out);
+
+extern "C" int vppx_inputs_ready_event(vppx_ctx *ctx, void *hip_event)
+{
+    VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
+    ctx->inputs_ev = hip_event;
+    return 0;
+}
+
 extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W,
                                  int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
                                  uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
 {
-    int rc;
     VPPX_ENTER(ctx);
     VPPX_PIPE_KEEP(ctx);
+    const int rc = vpp_rsgm_entry(ctx, nullptr, vp, rp, B, H, W, C, left, right, g, g_occ, nullptr, l_vpp, r_vpp, disp_out);
+    ctx->inputs_ev = nullptr; // one-shot, whatever happened
+    return rc;
+}
+
+extern "C" int vppx_occ_vpp_rsgm_dev(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp,
+                                     int B, int H, int W, int C, const uint8_t *left, const uint8_t *right, const float *g,
+                                     uint8_t *conf_out, uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
+{
+    VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
+    if (!op) { vppx_set_error("vppx_occ_vpp_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
+    const int rc = vpp_rsgm_entry(ctx, op, vp, rp, B, H, W, C, left, right, g, nullptr, conf_out, l_vpp, r_vpp, disp_out);
+    ctx->inputs_ev = nullptr;
+    return rc;
+}
+
+static int vpp_rsgm_entry(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
+                          int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                          uint8_t *conf_out, uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
+{
+    int rc;
+    if ((rc = lockstep_check(ctx))) return rc;
     if (!vp || !rp || !left || !right || !g || !disp_out) { vppx_set_error("vppx_vpp_rsgm: NULL argument"); return VPPX_E_INVALID_ARG; }
     if ((rc = check_frames(B, H, W, C))) return rc;
     if ((rc = check_vpp_params(*vp))) return rc;
     if ((rc = check_rsgm_params(*rp))) return rc;
+    if (ctx->inputs_ev && !pipeline_applies(ctx)) { // not pipelined: the inputs event is simply waited for on the launch stream
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream, (hipEvent_t)ctx->inputs_ev, 0));
+        ctx->inputs_ev = nullptr;
+    }
     const int nsub = (ctx->stage_timing || ctx->is_child) ? 1 : (B >= 2 * ctx->nsub ? ctx->nsub : 1);
     if (nsub <= 1 && ctx->graph_mode && !ctx->stage_timing) {
         // hipGraph replay: launch-bound small batches pay ~40 kernel launches per call otherwise
@@ -920,18 +1051,13 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
         memset(&key, 0, sizeof(key));
         key.B = B; key.H = H; key.W = W; key.C = C; key.vp = *vp; key.rp = *rp;
         key.ptr[0] = left; key.ptr[1] = right; key.ptr[2] = g; key.ptr[3] = g_occ; key.ptr[4] = l_vpp; key.ptr[5] = r_vpp;
-        key.ptr[6] = disp_out;
+        key.ptr[6] = disp_out; key.ptr[7] = conf_out;
+        key.has_op = op ? 1 : 0;
+        if (op) key.op = *op;
         key.stream = (void *)ctx->stream;
         key.ws_gen = ctx->ws_gen;
         // the graph does not contain the penalty-table upload: it must still be the table of these parameters
         const bool lut_ok = ctx->lut_valid && ctx->lut_p2min == rp->p2min && ctx->lut_gamma == rp->gamma && ctx->lut_alpha == rp->alpha;
-        if (ctx->vert3_err && ctx->vert3_err[0] && ctx->gexec) {
-            // the captured graph holds the fused launch that just lost its lock step: drop it (the eager call below
-            // reports the failure once and moves the context to the 8-path layout)
-            (void)hipGraphExecDestroy(ctx->gexec);
-            ctx->gexec = nullptr;
-            ctx->have_gkey = false;
-        }
         if (lut_ok && ctx->gexec && ctx->have_gkey && memcmp(&key, &ctx->gkey, sizeof(key)) == 0) {
             VPPX_HIP(hipGraphLaunch(ctx->gexec, ctx->stream));
             ctx->graph_replays++;
@@ -943,11 +1069,17 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
             hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 ctx->capturing = true;
-                rc = vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+                rc = vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
                 ctx->capturing = false;
                 hipGraph_t graph = nullptr;
                 e = hipStreamEndCapture(ctx->stream, &graph);
-                if (rc == 0 && e == hipSuccess && graph) {
+                if (rc != 0) { // the call itself failed (its message stands): that is not "capture impossible"
+                    if (graph) (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();
+                    ctx->have_lastkey = false;
+                    return rc;
+                }
+                if (e == hipSuccess && graph) {
                     e = hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0);
                     (void)hipGraphDestroy(graph);
                     if (e == hipSuccess) {
@@ -966,15 +1098,15 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
             // capture is not possible here (e.g. the legacy default stream): stay on the eager path
             (void)hipGetLastError();
             ctx->graph_mode = false;
-            return vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+            return vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
         }
-        rc = vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+        rc = vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
         key.ws_gen = ctx->ws_gen; // the workspace as this call left it
         ctx->lastkey = key;
         ctx->have_lastkey = (rc == 0);
         return rc;
     }
-    if (nsub <= 1) return vpp_rsgm_one(ctx, vp, rp, B, H, W, C, left, right, g, g_occ, l_vpp, r_vpp, disp_out);
+    if (nsub <= 1) return vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
     // Frames are independent: split the batch over child contexts (own stream + arena).  The
     // latency-bound stages of one part (VPP replay, post-processing) then overlap the
     // bandwidth-bound stages of another (aggregation stores, sum/WTA loads).
@@ -998,8 +1130,9 @@ extern "C" int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const V
         VPPX_HIP(hipStreamWaitEvent(c->stream, ctx->ev_fork, 0));
         VppxVppParams v2 = *vp;
         v2.seed = vp->seed + (uint32_t)lo; // frame f keeps srand(seed + f) whatever the split
-        rc = vpp_rsgm_one(c, &v2, rp, nb, H, W, C, left + (size_t)lo * fpx * C, right + (size_t)lo * fpx * C,
+        rc = vpp_rsgm_one(c, op, &v2, rp, nb, H, W, C, left + (size_t)lo * fpx * C, right + (size_t)lo * fpx * C,
                           g + (size_t)lo * fpx, g_occ ? g_occ + (size_t)lo * fpx : nullptr,
+                          conf_out ? conf_out + (size_t)lo * fpx : nullptr,
                           l_vpp ? l_vpp + (size_t)lo * fpx * C : nullptr, r_vpp ? r_vpp + (size_t)lo * fpx * C : nullptr,
                           disp_out + (size_t)lo * fpx);
         if (rc) return rc;
@@ -1103,25 +1236,18 @@ extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, 
                                             double l, double g, double th_conf, double th_filter, uint8_t *conf_out)
 {
     int rc;
-    VPPX_ENTER(ctx);
-    VPPX_PIPE_KEEP(ctx);
+    VPPX_ENTER(ctx); // (like every entry point but the two pipelined ones: the next front stage waits for the launch stream)
+    if ((rc = lockstep_check(ctx))) return rc;
     if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
     const size_t n = (size_t)B * H * W;
     float *omap;
     u8 *conf;
     if ((rc = ws_get(ctx, WS_OCC_OMAP, n, &omap))) return rc;
     if ((rc = ws_get(ctx, WS_OCC_CONF, n, &conf))) return rc;
-    FrontGuard guard{ctx};
-    if (pipeline_applies(ctx) && (rc = front_begin(ctx))) return rc; // part of the next fused call's front stage
-    if ((rc = occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out))) return rc;
-    return front_end(ctx);
+    return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out);
 }
 
-// Cross-call pipelining for streams of batches through occlusion_heuristic + vpp_rsgm (bench.py, serving loops): the
-// front stage of a call runs on a second stream as soon as the previous call's aggregation is done, next to that call's
-// sum / WTA and post kernels.  Results keep the launch stream's order (it waits for the front stage); INPUTS must be
-// ready when the call is made: a tensor produced by work queued on the launch stream after the previous call is not
-// waited for.  Off by default.
+// Cross-call pipelining of vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev (contract: include/vppx.h).  Off by default.
 extern "C" int vppx_set_pipeline(vppx_ctx *ctx, int on)
 {
     int rc;

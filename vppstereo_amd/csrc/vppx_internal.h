@@ -86,6 +86,7 @@ enum WsSlot {
     WS_STAGE_F,
     WS_OCC_OMAP,
     WS_OCC_CONF,
+    WS_OCC_OUT,       // the mask of the fused occlusion + VPP + rSGM call (library-owned: the front stage never writes caller memory)
     WS_OCC_TMP,       // unwarp scratch of the occlusion heuristic (its own slot: with vppx_set_pipeline it runs next to the previous call's speckle filter, which owns WS_LABEL)
     WS_NHINTS,
     WS_HANDOFF_H,    // hints / valid at feature resolution (hand-off kernels)
@@ -122,10 +123,25 @@ struct vppx_ctx {
     bool pipe_call = false;        // the running vpp_rsgm call is pipelined (record ev_agg_done after its aggregation)
     bool have_agg_done = false;
     hipStream_t stream_front = nullptr, main_saved = nullptr;
-    hipEvent_t ev_agg_done = nullptr, ev_front_done = nullptr;
-    unsigned *vert3_err = nullptr; // pinned host word the fused vertical kernel sets when a wave gave up waiting
+    hipEvent_t ev_agg_done = nullptr, ev_front_done = nullptr, ev_inputs_auto = nullptr;
+    void *inputs_ev = nullptr;     // caller's "inputs of the next call are ready" event (vppx_inputs_ready_event), one-shot
+    // front-stage results the caller asked for (mask, patterned pair): computed into library-owned buffers on the front
+    // stream, copied to the caller's memory on the LAUNCH stream once it has waited for the front stage
+    struct PipeCopy { void *dst; const void *src; size_t bytes; } pipe_copy[3];
+    int n_pipe_copy = 0;
+    unsigned *vert3_err = nullptr; // pinned host word the fused vertical kernel sets (to its launch serial) when a wave gave up waiting
     bool vert3_broken = false;     // set once vert3_err was seen (or the XCD probe failed): the context stays on the line-parallel kernel
     bool vert3_probed = false;     // rsgm_vert3_probe has run on this context's device
+    long lockstep_failures = 0;    // fused launches that reported a lost lock step (vppx_lockstep_failures)
+    struct V3Caps {                // what rsgm_vert3_probe found out about the device and this build of the kernels
+        bool ok = false;
+        int nxcd = 0, cus_per_xcd = 0;
+        int blocks_per_cu[4] = {0, 0, 0, 0}; // D = 64, 128, 192, 256
+        int wall_khz = 100000;     // rate of s_memrealtime
+        int timeout_ms = 250;      // bound of one wait for a neighbour (VPPX_V3_TIMEOUT_MS)
+        unsigned spin_limit = 0;   // polls per wait, 0 = unbounded (VPPX_V3_SPIN_LIMIT: tests force the give-up path with 1)
+        unsigned serial = 0;       // serial of the last fused launch
+    } v3;
     DevBuf ws[WS_NUM];
     std::string devname;
     // libc-like stream state of the single-frame scans
@@ -152,7 +168,9 @@ struct vppx_ctx {
         int B, H, W, C;
         VppxVppParams vp;
         VppxRsgmParams rp;
-        const void *ptr[7];
+        const void *ptr[8];
+        VppxOccParams op;
+        int has_op;
         void *stream;
         unsigned long ws_gen;
     };
@@ -194,6 +212,7 @@ enum {
     ST_WTA_RIGHT,
     ST_MEDIAN_INTERP,
     ST_POST,
+    ST_OCC,
     ST_COUNT
 };
 void stage_begin(vppx_ctx *ctx);
@@ -224,6 +243,7 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
 // band-marching vertical/diagonal paths (3 summed paths per pass, one byte per cell)
 int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev, bool *ok);
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2);
+bool rsgm_vert3_fits(const vppx_ctx *ctx, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err);

@@ -78,22 +78,44 @@ class Engine:
         return out
 
     def vpp_rsgm(self, left, right, hints, g_occ=None, out=None, l_vpp=None, r_vpp=None, seed=1, vpp_kw=None,
-                 rsgm_kw=None):
-        """The whole hot path for a batch: one call, no host round trips, no synchronisation."""
+                 rsgm_kw=None, occ_out=None, inputs_ready=None):
+        """The whole hot path for a batch: one call, no host round trips, no synchronisation.
+
+        g_occ: None, a uint8 [B,H,W] mask tensor, or -- test.py:154 with --maskocc in the same call --
+        ``"occlusion_heuristic"`` / a dict of its parameters (rx, ry, l, g, th_conf, th_filter): the mask is then
+        computed on the way (vppx_occ_vpp_rsgm_dev) and also written to `occ_out` when given.
+        inputs_ready: a ``torch.cuda.Event`` recorded after the work that produced this call's input tensors.  Only
+        matters with `set_pipeline(True)`: the front stage then waits for that event instead of for everything queued on
+        the current stream, and can overlap the previous call's tail."""
         torch = self.torch
-        B, H, W, Cc = self._chk_pair(left, right, hints, g_occ)
+        heuristic = isinstance(g_occ, (str, dict))
+        if isinstance(g_occ, str) and g_occ != "occlusion_heuristic":
+            raise ValueError("g_occ: expected a mask tensor, None, 'occlusion_heuristic' or a dict of its parameters")
+        B, H, W, Cc = self._chk_pair(left, right, hints, None if heuristic else g_occ)
         if out is None:
             out = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
         self._chk(out, torch.float32, 3, "out", (B, H, W))
         for t, n in ((l_vpp, "l_vpp"), (r_vpp, "r_vpp")):
             if t is not None:
                 self._chk(t, torch.uint8, 4, n, left.shape)
+        if occ_out is not None:
+            if not heuristic:
+                raise ValueError("occ_out is the mask output of g_occ='occlusion_heuristic'")
+            self._chk(occ_out, torch.uint8, 3, "occ_out", (B, H, W))
         self._bind_stream()
         vp = _lib.vpp_params(seed=int(seed) & 0xFFFFFFFF, **(vpp_kw or {}))
         rp = _lib.rsgm_params(**(rsgm_kw or {}))
-        _lib.check(self.lib.vppx_vpp_rsgm_dev(self.ctx.handle, C.byref(vp), C.byref(rp), B, H, W, Cc, _ptr(left),
-                                              _ptr(right), _ptr(hints), _ptr(g_occ), _ptr(l_vpp), _ptr(r_vpp),
-                                              _ptr(out)))
+        if inputs_ready is not None:
+            _lib.check(self.lib.vppx_inputs_ready_event(self.ctx.handle, C.c_void_p(inputs_ready.cuda_event)))
+        if heuristic:
+            op = _lib.occ_params(**(g_occ if isinstance(g_occ, dict) else {}))
+            _lib.check(self.lib.vppx_occ_vpp_rsgm_dev(self.ctx.handle, C.byref(op), C.byref(vp), C.byref(rp), B, H, W, Cc,
+                                                      _ptr(left), _ptr(right), _ptr(hints), _ptr(occ_out), _ptr(l_vpp),
+                                                      _ptr(r_vpp), _ptr(out)))
+        else:
+            _lib.check(self.lib.vppx_vpp_rsgm_dev(self.ctx.handle, C.byref(vp), C.byref(rp), B, H, W, Cc, _ptr(left),
+                                                  _ptr(right), _ptr(hints), _ptr(g_occ), _ptr(l_vpp), _ptr(r_vpp),
+                                                  _ptr(out)))
         return out
 
     def occlusion_heuristic(self, hints, rx=9, ry=7, l=2, g=0.4375, th_conf=1, th_filter=0.1, out=None):
@@ -235,14 +257,25 @@ class Engine:
                                                 int(bool(little_endian)), _ptr(out)))
         return out
 
+    def synchronize(self):
+        """Wait for torch's current stream (the stream the library launches on) and check the health of the asynchronous
+        hot path: raises `VppxError` when a fused aggregation launch lost its lock step, i.e. when disparities returned
+        since the last check are void (include/vppx.h, vppx_status).  Callers that synchronise through torch
+        (`torch.cuda.synchronize()`, `.cpu()`, `.item()`) call `status()` afterwards instead."""
+        self._bind_stream()
+        self.ctx.synchronize()
+
+    def status(self):
+        """Non-blocking: raise `VppxError` if any fused aggregation launch finished so far lost its lock step."""
+        self.ctx.status()
+
     def set_pipeline(self, enable=True):
-        """Cross-call pipelining for streams of batches through `occlusion_heuristic` + `vpp_rsgm`: the front stage of a
-        call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the previous call's
-        aggregation is done, next to that call's sum / WTA and post kernels.  Outputs keep torch's stream order; INPUTS
-        must be ready when the call is made (tensors produced by work queued on the current stream after the previous call
-        are not waited for), and the buffers the front stage writes (`occlusion_heuristic(out=)`, `l_vpp`, `r_vpp`) must be
-        persistent: a tensor allocated per call may reuse memory that work still queued on the current stream has not
-        read yet (torch's caching allocator orders reuse on the current stream only).  Off by default."""
+        """Cross-call pipelining for streams of batches through `vpp_rsgm`: the front stage of a call (occlusion
+        heuristic, VPP, pad + gray, census) runs on a second stream as soon as the previous call's aggregation is done,
+        next to that call's sum / WTA and post kernels.  Safe by construction (include/vppx.h): outputs keep torch's
+        stream order and are written on the current stream only (per-call allocated tensors are fine); the front stage
+        waits for everything queued on the current stream before the call unless the caller passes `inputs_ready=`,
+        the event after which this call's inputs exist -- only then is there anything to overlap.  Off by default."""
         _lib.check(self.lib.vppx_set_pipeline(self.ctx.handle, int(bool(enable))))
 
     def set_graph_mode(self, enable=True):
