@@ -288,6 +288,14 @@ int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W, const floa
                                   double g, double th_conf, double th_filter, uint8_t *conf_out);
 int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l,
                                  double g, double th_conf, double th_filter, uint8_t *conf_out);
+/* Both elements of the reference's return value (filter.py:283-292): dmap_out (float32 [B,H,W], may be NULL) = the
+ * filtered hints un-warped and passed through interpolate_disparity(dmap, 3), conf_out = the mask.  The reference's
+ * interpolate_disparity indexes dmap[y, x +- 1] without a bounds test (filter.py:223,229): column -1 wraps to W-1, column W
+ * is the first pixel of the next row; the read past the end of the last row is undefined there and taken as 0 here. */
+int vppx_occlusion_heuristic_full_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l,
+                                       double g, double th_conf, double th_filter, float *dmap_out, uint8_t *conf_out);
+int vppx_occlusion_heuristic_full_dev(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l,
+                                      double g, double th_conf, double th_filter, float *dmap_out, uint8_t *conf_out);
 
 /* ---- measurement helpers (bench.py) ------------------------------------------------------- */
 /* Time `iters` back-to-back launches of the dominant kernel (8-path aggregation) on the

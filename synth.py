@@ -72,3 +72,34 @@ def uniform_random_pair(H, W, D, p_hints, seed=0, channels=3):
     m = rng.random((H, W)) < p_hints
     g[m] = rng.uniform(1, D - 1, size=int(m.sum())).astype(np.float32)
     return l, r, g
+
+
+# ---------------------------------------------------------------------------------------------------------
+# splitmix64: the repository's own generator (Steele, Lea, Flood 2014) for fixtures whose inputs must be the
+# same on every machine and numpy version (tests/golden/vpp_anchors_splitmix.json)
+# ---------------------------------------------------------------------------------------------------------
+def splitmix64(seed, n):
+    """The first n outputs of splitmix64 seeded with `seed`, as uint64."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _sm_unit(seed, n):
+    """n doubles in [0, 1) from the top 53 bits of the splitmix64 outputs."""
+    return (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def anchor_inputs_splitmix(H=540, W=960, D=192, p=0.03):
+    """Uniform-random pair, p hints uniform in [1, D-1), a 25 % occlusion mask: the SURVEY App. D recipe with
+    splitmix64 in place of numpy's Generator.  Returns l, r, g, occ0, occ1."""
+    n = H * W
+    l = splitmix64(101, (n * 3 + 7) // 8).view(np.uint8)[: n * 3].reshape(H, W, 3).copy()
+    r = splitmix64(202, (n * 3 + 7) // 8).view(np.uint8)[: n * 3].reshape(H, W, 3).copy()
+    m = _sm_unit(303, n) < p
+    vals = (1.0 + _sm_unit(404, n) * (D - 2)).astype(np.float32)
+    g = np.where(m, vals, np.float32(0)).astype(np.float32).reshape(H, W)
+    occ1 = (_sm_unit(505, n) < 0.25).astype(np.uint8).reshape(H, W)
+    return l, r, g, np.zeros((H, W), np.uint8), occ1

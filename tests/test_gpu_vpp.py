@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 import synth
-from test_oracle_vpp import _anchor_inputs, run_case
+from test_oracle_vpp import ANCHOR_SETS, load_anchors, run_case
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -113,12 +113,9 @@ def test_maxdist_vs_oracle_random_inputs(gpu):
             assert np.array_equal(b0, b1), (cfg, int((b0 != b1).sum()))
 
 
-def test_maxdist_full_size_anchor_hash(gpu):
-    with open(os.path.join(GOLDEN, "vpp_anchors.json")) as f:
-        meta = json.load(f)
-    l, r, g, occ0, occ1 = _anchor_inputs(meta)
-    if _sha(l) != meta["inputs"]["l"] or _sha(g) != meta["inputs"]["g"]:
-        pytest.skip("numpy Generator stream differs from the one the anchors were made with")
+@pytest.mark.parametrize("anchors", ANCHOR_SETS)
+def test_maxdist_full_size_anchor_hash(gpu, anchors):
+    meta, (l, r, g, occ0, occ1) = load_anchors(anchors)
     H, W = meta["H"], meta["W"]
     c = {c["name"]: c for c in meta["cases"]}["maxdist_occ1"]
     a, b = l.copy(), r.copy()
@@ -126,13 +123,10 @@ def test_maxdist_full_size_anchor_hash(gpu):
     assert n == c["n_hints"] and _sha(a) == c["l"] and _sha(b) == c["r"]
 
 
-def test_rnd_full_size_anchor_hashes(gpu):
-    """540x960x3, 3 % hints: SHA-256 of the reference's outputs."""
-    with open(os.path.join(GOLDEN, "vpp_anchors.json")) as f:
-        meta = json.load(f)
-    l, r, g, occ0, occ1 = _anchor_inputs(meta)
-    if _sha(l) != meta["inputs"]["l"] or _sha(g) != meta["inputs"]["g"]:
-        pytest.skip("numpy Generator stream differs from the one the anchors were made with")
+@pytest.mark.parametrize("anchors", ANCHOR_SETS)
+def test_rnd_full_size_anchor_hashes(gpu, anchors):
+    """540x960x3, 3 % hints: SHA-256 of the reference's outputs (the same recipe on splitmix64 inputs)."""
+    meta, (l, r, g, occ0, occ1) = load_anchors(anchors)
     H, W = meta["H"], meta["W"]
     by = {c["name"]: c for c in meta["cases"]}
     for name, occ, args, seed in (("rnd_occ0", occ0, (False, 3, 1, 0.4, 0.0), 1), ("rnd_occ1", occ1, (False, 3, 1, 0.4, 0.0), 1),
@@ -222,6 +216,34 @@ def test_occlusion_heuristic_golden():
     for i in range(2):
         _, conf = vfilter.occlusion_heuristic(G[f"occ{i}_in"])
         assert np.array_equal(conf, G[f"occ{i}_conf"]), i
+
+
+def test_occlusion_heuristic_returns_the_references_pair():
+    """Element [0] (filter.py:283-292: filtered hints, un-warped, interpolate_disparity(dmap, 3)) next to the mask, against
+    the oracle's restatement, including the unguarded dmap[y, x +- 1] reads at both borders (SURVEY C-8: column -1 wraps
+    to W-1, column W is the next row's first pixel)."""
+    from vppstereo_amd import filter as vfilter
+    rng = np.random.default_rng(5)
+    for i, (h, w, p) in enumerate([(24, 64, 0.5), (16, 48, 0.8), (33, 70, 0.3), (135, 240, 0.05)]):
+        d = np.zeros((h, w), np.float32)
+        m = rng.random((h, w)) < p
+        d[m] = (rng.integers(8, 80, int(m.sum())) * 0.125).astype(np.float32)   # small disparities: many land next to each other
+        d[h // 3: 2 * h // 3, w // 3: w // 2][d[h // 3: 2 * h // 3, w // 3: w // 2] > 0] += 9.0
+        d[:, 0] = np.where(rng.random(h) < 0.5, 0, d[:, 0])       # zeros and values in the border columns
+        want_d, want_c = oracle.occlusion_heuristic(d)
+        got_d, got_c = vfilter.occlusion_heuristic(d)
+        assert got_d.dtype == np.float32 and got_d.shape == d.shape
+        assert np.array_equal(got_c, want_c), i
+        assert np.array_equal(got_d, want_d), (i, int((got_d != want_d).sum()))
+        assert (want_d != 0).any()
+    filled = 0
+    for _ in range(3):   # dense small maps: the interpolation actually fills something, also across the row ends
+        d = (rng.integers(0, 3, (12, 20)) * rng.integers(8, 12, (12, 20)) * 0.125).astype(np.float32)
+        want_d, _ = oracle.occlusion_heuristic(d)
+        got_d, _ = vfilter.occlusion_heuristic(d)
+        assert np.array_equal(got_d, want_d)
+        filled += int((want_d != 0).sum())
+    assert filled > 0
 
 
 def test_batched_vpp_is_sharding_independent():

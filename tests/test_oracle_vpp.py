@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
+import synth
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -81,6 +82,27 @@ def test_golden_cases_cover_every_branch(vpp_golden):
             assert any(c[key] == v for c in cases), (key, v)
 
 
+ANCHOR_SETS = ["vpp_anchors.json", "vpp_anchors_splitmix.json"]
+
+
+def load_anchors(name):
+    """(meta, inputs) of one anchor set.  vpp_anchors.json = SURVEY App. D with numpy's Generator: skipped if this numpy
+    draws another stream; vpp_anchors_splitmix.json = the same recipe on the repository's own splitmix64 inputs
+    (tests/golden/make_vpp_anchors_splitmix.py): never skips, a hash mismatch of the inputs is a failure."""
+    with open(os.path.join(GOLDEN, name)) as f:
+        meta = json.load(f)
+    if "splitmix" in name:
+        inp = synth.anchor_inputs_splitmix(meta["H"], meta["W"], meta["D"], meta["p"])
+        assert _sha(inp[0]) == meta["inputs"]["l"] and _sha(inp[1]) == meta["inputs"]["r"]
+        assert _sha(inp[2]) == meta["inputs"]["g"] and _sha(inp[4]) == meta["inputs"]["occ1"]
+        return meta, inp
+    inp = _anchor_inputs(meta)
+    if _sha(inp[0]) != meta["inputs"]["l"] or _sha(inp[2]) != meta["inputs"]["g"]:
+        pytest.skip("numpy Generator stream differs from the one the App. D anchors were made with "
+                    "(the splitmix set covers the same cases)")
+    return meta, inp
+
+
 def _anchor_inputs(meta):
     H, W, D, p = meta["H"], meta["W"], meta["D"], meta["p"]
     rng = np.random.default_rng(0)
@@ -94,13 +116,10 @@ def _anchor_inputs(meta):
     return l, r, g, occ0, occ1
 
 
-def test_oracle_matches_full_size_anchors():
+@pytest.mark.parametrize("anchors", ANCHOR_SETS)
+def test_oracle_matches_full_size_anchors(anchors):
     """540x960 anchors of SURVEY.md App. D (hashes of the reference's outputs)."""
-    with open(os.path.join(GOLDEN, "vpp_anchors.json")) as f:
-        meta = json.load(f)
-    l, r, g, occ0, occ1 = _anchor_inputs(meta)
-    if _sha(l) != meta["inputs"]["l"] or _sha(g) != meta["inputs"]["g"]:
-        pytest.skip("numpy Generator stream differs from the one the anchors were made with")
+    meta, (l, r, g, occ0, occ1) = load_anchors(anchors)
     H, W = meta["H"], meta["W"]
     for c in meta["cases"]:
         a, b = l.copy(), r.copy()

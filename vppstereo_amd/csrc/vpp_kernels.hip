@@ -1760,8 +1760,40 @@ __global__ void __launch_bounds__(256) occ_final_kernel(const int *__restrict__ 
     out[i] = t < 0 ? 1 : (u8)(t & 1); // default 1 (filter.py:101)
 }
 
+// Element [0] of occlusion_heuristic (filter.py:283-292): left_unwarp of the filtered omap (:51-79, last writer in raster
+// order wins: the same winner conf_unwarp has, kept in tmp) followed by interpolate_disparity(dmap, 3) (:197-243).  With
+// n = 1 that pass only ever changes a zero pixel whose two flat-memory neighbours are positive and less than 1 apart (the
+// neighbours it rewrites get their own values back), and no pixel it reads has been changed before it is read, so the
+// sequential pass equals this gather.  The reference indexes dmap[y, x +- 1] without a bounds test (SURVEY C-8): x - 1 = -1
+// wraps to column W - 1 of the same row, x + 1 = W is the first pixel of the next row; past the end of the frame is
+// undefined there and reads as 0 here (like the oracle).
+__global__ void __launch_bounds__(256) occ_dmap_kernel(const int *__restrict__ tmp, const float *__restrict__ omap,
+                                                       float *__restrict__ dmap_out, int H, int W)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= W) return;
+    const size_t fb = (size_t)f * H * W;
+    auto unwarped = [&](int yy, int xx) -> float {
+        const size_t row = fb + (size_t)yy * W;
+        const int t = tmp[row + xx];
+        return t < 0 ? 0.0f : omap[row + (t >> 1)];
+    };
+    float u = unwarped(y, x);
+    if (u == 0.0f) {
+        const float nl = x > 0 ? unwarped(y, x - 1) : unwarped(y, W - 1);
+        const float nr = x < W - 1 ? unwarped(y, x + 1) : (y < H - 1 ? unwarped(y + 1, 0) : 0.0f);
+        if (nl > 0 && nr > 0 && fabs(__dsub_rn((double)nl, (double)nr)) < 1.0) {
+            const double m = __ddiv_rn(__dsub_rn((double)nr, (double)nl), 2.0);
+            const double q = __dsub_rn((double)nl, __dmul_rn(m, -1.0));
+            u = (float)__dadd_rn(__dmul_rn(m, 0.0), q);
+        }
+    }
+    dmap_out[fb + (size_t)y * W + x] = u;
+}
+
 int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,
-               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out)
+               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out, float *dmap_out)
 {
     const size_t n = (size_t)B * H * W;
     dim3 grid((W + 255) / 256, H, B);
@@ -1778,5 +1810,9 @@ int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, i
     VPPX_CHECK_LAUNCH();
     occ_final_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(tmp, conf_out, n);
     VPPX_CHECK_LAUNCH();
+    if (dmap_out) {
+        occ_dmap_kernel<<<grid, 256, 0, ctx->stream>>>(tmp, omap, dmap_out, H, W);
+        VPPX_CHECK_LAUNCH();
+    }
     return 0;
 }

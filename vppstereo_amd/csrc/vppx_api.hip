@@ -1235,6 +1235,13 @@ extern "C" int vppx_png_decode_dev(vppx_ctx *ctx, int n_files, const uint8_t *bl
 extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,
                                             double l, double g, double th_conf, double th_filter, uint8_t *conf_out)
 {
+    return vppx_occlusion_heuristic_full_dev(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, nullptr, conf_out);
+}
+
+extern "C" int vppx_occlusion_heuristic_full_dev(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,
+                                                 double l, double g, double th_conf, double th_filter, float *dmap_out,
+                                                 uint8_t *conf_out)
+{
     int rc;
     VPPX_ENTER(ctx); // (like every entry point but the two pipelined ones: the next front stage waits for the launch stream)
     if ((rc = lockstep_check(ctx))) return rc;
@@ -1244,7 +1251,7 @@ extern "C" int vppx_occlusion_heuristic_dev(vppx_ctx *ctx, int B, int H, int W, 
     u8 *conf;
     if ((rc = ws_get(ctx, WS_OCC_OMAP, n, &omap))) return rc;
     if ((rc = ws_get(ctx, WS_OCC_CONF, n, &conf))) return rc;
-    return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out);
+    return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out, dmap_out);
 }
 
 // Cross-call pipelining of vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev (contract: include/vppx.h).  Off by default.
@@ -1261,15 +1268,24 @@ extern "C" int vppx_set_pipeline(vppx_ctx *ctx, int on)
 extern "C" int vppx_occlusion_heuristic_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,
                                              double l, double g, double th_conf, double th_filter, uint8_t *conf_out)
 {
+    return vppx_occlusion_heuristic_full_host(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, nullptr, conf_out);
+}
+
+extern "C" int vppx_occlusion_heuristic_full_host(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry,
+                                                  double l, double g, double th_conf, double th_filter, float *dmap_out,
+                                                  uint8_t *conf_out)
+{
     int rc;
     VPPX_ENTER(ctx);
     if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
     const size_t n = (size_t)B * H * W;
-    void *dh, *dc;
+    void *dh, *dc, *dd = nullptr;
     if ((rc = upload(ctx, WS_STAGE_A, hints, n * sizeof(float), &dh))) return rc;
     if ((rc = ws_reserve(ctx, WS_STAGE_B, n, &dc))) return rc;
-    if ((rc = vppx_occlusion_heuristic_dev(ctx, B, H, W, (const float *)dh, rx, ry, l, g, th_conf, th_filter, (u8 *)dc))) return rc;
+    if (dmap_out && (rc = ws_reserve(ctx, WS_STAGE_C, n * sizeof(float), &dd))) return rc;
+    if ((rc = vppx_occlusion_heuristic_full_dev(ctx, B, H, W, (const float *)dh, rx, ry, l, g, th_conf, th_filter, (float *)dd, (u8 *)dc))) return rc;
     if ((rc = download(ctx, conf_out, dc, n))) return rc;
+    if (dmap_out && (rc = download(ctx, dmap_out, dd, n * sizeof(float)))) return rc;
     VPPX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

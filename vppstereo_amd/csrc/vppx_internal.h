@@ -298,4 +298,4 @@ int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const lon
 
 // occ_kernels (in vpp_kernels.hip)
 int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,
-               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out);
+               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out, float *dmap_out = nullptr);
