@@ -1,9 +1,13 @@
-#!/usr/bin/env python3
-"""Print a short summary of bench.py's JSON line read from stdin (experiment helper)."""
-import json, sys
-tag = " ".join(sys.argv[1:])
-for line in sys.stdin:
-    if line.startswith("{"):
-        d = json.loads(line)
-        print(tag, "Mdisp/s", d["value"], "ms/step", d["ms_per_step"], "agg_ms", d["roofline"]["kernel_ms"],
-              {k: v for k, v in d["stage_ms"].items() if v > 0.2})
+"""tools/bench_line.py < bench.json : the handful of numbers of a bench line that matter while iterating."""
+import json
+import sys
+
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r = d["roofline"]
+dk = r.get("dominant_kernel", {})
+print(sys.argv[1] if len(sys.argv) > 1 else "", "ms/step", d["ms_per_step"], "unpipelined", d.get("ms_per_step_unpipelined"),
+      "frac", r["frac"], "| kernel_ms", dk.get("kernel_ms"), "b2b", dk.get("kernel_ms_back_to_back"), "we",
+      dk.get("other_aggregation_launch_ms"), "| b1", d["b1"]["ms_per_frame"], "| no-occ", d.get("ms_per_step_without_g_occ"))
+print("   stages", d["stage_ms"])
+for o in d.get("other_configs") or []:
+    print("   ", o)

@@ -1166,11 +1166,13 @@ __device__ __forceinline__ void sgm_update_split(u32 (&L)[NP], const u32 (&C)[NP
     for (int i = 0; i < NP; i++) m[i] += P1pk;
 #pragma unroll
     for (int i = 0; i < NP; i++) m[i] = pk_min3_small(m[i], L[i], t2);
-#pragma unroll
-    for (int i = 0; i < NP; i++) m[i] += C[i];
+    // + C - min as ONE three-operand add (v_add3_u32) with the negated packed minimum: every half of m + C is >= the
+    // minimum, so no borrow crosses the halves and the 32-bit sum is the packed difference
+    u32 negmin = 0u - minpk;
+    asm volatile("" : "+v"(negmin)); // (keeps LLVM from turning the sum back into an add and a subtract)
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        m[i] -= minpk;
+        m[i] = m[i] + C[i] + negmin;
         L[i] = m[i];
     }
 #pragma unroll
@@ -1398,18 +1400,29 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
                 e[4 * q] = er.p[q].x; e[4 * q + 1] = er.p[q].y; e[4 * q + 2] = er.p[q].z; e[4 * q + 3] = er.p[q].w;
             }
             e[NP] = er.m;
-            // the two diagonal states move one pixel sideways: inside the wave by ds_bpermute, at its ends from the records
+            // the two diagonal states move one pixel sideways: inside the wave by ds_bpermute, at its ends from the records.
+            // The edge lanes take the record with MOVES UNDER AN EXEC MASK (two divergent regions of 13 full-rate v_mov each)
+            // rather than 26 v_cndmask, which issue at half rate on gfx950; the empty asm keeps hipcc from turning the
+            // regions back into selects.
 #pragma unroll
             for (int i = 0; i < NP; i++) {
-                const u32 s1 = (u32)__builtin_amdgcn_ds_bpermute(bp_left, (int)L1[i]);
-                const u32 s2 = (u32)__builtin_amdgcn_ds_bpermute(bp_right, (int)L2[i]);
-                L1[i] = (g == 0) ? e[i] : s1;
-                L2[i] = (g == 7) ? e[i] : s2;
+                L1[i] = (u32)__builtin_amdgcn_ds_bpermute(bp_left, (int)L1[i]);
+                L2[i] = (u32)__builtin_amdgcn_ds_bpermute(bp_right, (int)L2[i]);
             }
-            const u32 m1 = (u32)__builtin_amdgcn_ds_bpermute(bp_left, (int)mn1);
-            const u32 m2 = (u32)__builtin_amdgcn_ds_bpermute(bp_right, (int)mn2);
-            mn1 = (g == 0) ? e[NP] : m1;
-            mn2 = (g == 7) ? e[NP] : m2;
+            mn1 = (u32)__builtin_amdgcn_ds_bpermute(bp_left, (int)mn1);
+            mn2 = (u32)__builtin_amdgcn_ds_bpermute(bp_right, (int)mn2);
+            if (g == 0) {
+                asm volatile("; NW edge from the left wave's record");
+#pragma unroll
+                for (int i = 0; i < NP; i++) L1[i] = e[i];
+                mn1 = e[NP];
+            }
+            if (g == 7) {
+                asm volatile("; NE edge from the right wave's record");
+#pragma unroll
+                for (int i = 0; i < NP; i++) L2[i] = e[i];
+                mn2 = e[NP];
+            }
         }
         // ---- last row's bytes (everything older has just been drained: this store has a whole row to complete)
         store_pend();

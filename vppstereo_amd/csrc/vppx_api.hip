@@ -174,8 +174,14 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
         // bounds of one neighbour wait in the fused aggregation kernel: milliseconds of wall clock (the bound that counts)
         // and, for tests that must see the give-up path, a number of polls (1 = give up at the first record not there yet)
+        e = getenv("VPPX_PIPE_EARLY");
+        if (e) ctx->pipe_early = atoi(e) != 0;
+        e = getenv("VPPX_WE_OVERLAP");
+        if (e) ctx->we_overlap = atoi(e);
         e = getenv("VPPX_V3_TIMEOUT_MS");
         if (e && atoi(e) > 0) ctx->v3.timeout_ms = atoi(e);
+        e = getenv("VPPX_V3_IGNORE_LOST");
+        if (e && atoi(e) > 0) ctx->v3.ignore_lost = true;
         e = getenv("VPPX_V3_SPIN_LIMIT");
         if (e && atoi(e) > 0) ctx->v3.spin_limit = (unsigned)atoi(e);
     }
@@ -207,6 +213,7 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (ctx->ev_front_done) (void)hipEventDestroy(ctx->ev_front_done);
     if (ctx->ev_inputs_auto) (void)hipEventDestroy(ctx->ev_inputs_auto);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_we) (void)hipStreamDestroy(ctx->stream_we);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
@@ -280,8 +287,9 @@ static int lockstep_check(vppx_ctx *ctx)
     if (!ctx->vert3_err || !ctx->vert3_err[0]) return 0;
     const unsigned serial = ctx->vert3_err[0];
     ctx->vert3_err[0] = 0;
-    ctx->vert3_broken = true;
     ctx->lockstep_failures++;
+    if (ctx->v3.ignore_lost) return 0; // measurement only (tools/agg_probe.py: the fused kernel's time without any neighbour wait)
+    ctx->vert3_broken = true;
     if (ctx->gexec) {
         (void)hipGraphExecDestroy(ctx->gexec);
         ctx->gexec = nullptr;
@@ -526,7 +534,25 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             }
             return r;
         };
-        if (which == 0 && vert3) {
+        if (which == 0 && vert3 && ctx->we_overlap > 0 && !ctx->capturing) {
+            // experiment (VPPX_WE_OVERLAP): W/E on a side stream (2: high priority) so that the fused kernel's first groups
+            // can start in the W/E launch's second, sparsely filled round
+            if (!ctx->stream_we) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                VPPX_HIP(hipStreamCreateWithPriority(&ctx->stream_we, hipStreamNonBlocking, ctx->we_overlap >= 2 ? hi : lo));
+            }
+            VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            VPPX_HIP(hipStreamWaitEvent(ctx->stream_we, ctx->ev_fork, 0));
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->stream_we;
+            rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11);
+            ctx->stream = main_stream;
+            if (rc) return rc;
+            VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream_we));
+            if ((rc = launch_vert(ctx->stream))) return rc;
+            VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        } else if (which == 0 && vert3) {
             // one after the other: both launches fill the chip, two streams only interleave them (measured: no gain)
             if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11))) return rc;
             if ((rc = launch_vert(ctx->stream))) return rc;
@@ -630,6 +656,16 @@ static int front_end(vppx_ctx *ctx)
     for (int i = 0; i < ctx->n_pipe_copy; i++)
         VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_pipe_copy = 0;
+    if (ctx->pipe_call && ctx->pipe_early) {
+        // From here on nothing of this call reads what a front stage writes, except the gray / census images the
+        // aggregation takes -- and those alternate between two sets by call parity.  The NEXT call's front stage may
+        // therefore start now, next to this call's aggregation (it fills the sparsely occupied second round of the W/E
+        // launch and the registers the fused kernel leaves free) instead of next to its sum / WTA kernel, which leaves no LDS.
+        // Set p is rewritten by front stage k+2, which waits for THIS event of call k+1, recorded on the in-order launch
+        // stream behind call k's aggregation.
+        VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
+        ctx->have_agg_done = true;
+    }
     return 0;
 }
 struct FrontGuard { // error paths: never leave the context on the front stream
@@ -653,12 +689,16 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const size_t ncell = npp * g.D;
     u8 *gl, *glv, *grv;
     u32 *cl, *cr_raw;
-    if ((rc = ws_get(ctx, WS_GRAY_L, npp, &gl))) return rc;
+    // (pipelined calls alternate between two sets of the images the aggregation reads: see front_end)
+    const bool alt = ctx->pipe_call && ctx->pipe_early && (ctx->pipe_parity & 1);
+    if (ctx->pipe_call) ctx->pipe_parity ^= 1;
+    if ((rc = ws_get(ctx, alt ? WS_GRAY_L2 : WS_GRAY_L, npp, &gl))) return rc;
     if ((rc = ws_get(ctx, WS_GRAY_LV, npp, &glv))) return rc;
     if ((rc = ws_get(ctx, WS_GRAY_RV, npp, &grv))) return rc;
-    if ((rc = ws_get(ctx, WS_CENSUS_L, npp, &cl))) return rc;
-    if ((rc = ws_get(ctx, WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
+    if ((rc = ws_get(ctx, alt ? WS_CENSUS_L2 : WS_CENSUS_L, npp, &cl))) return rc;
+    if ((rc = ws_get(ctx, alt ? WS_CENSUS_R2 : WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
     u32 *cr = cr_raw + 512;
+    ctx->last_gl = gl; ctx->last_cl = cl; ctx->last_cr = cr;
     {
         const u8 *imgs[3] = {left, left_vpp, right_vpp};
         u8 *grays[3] = {gl, glv, grv};
@@ -685,7 +725,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const void *vols[8];
     int nvol = 0, elem_bytes = 1;
     if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0, hints, validhints))) return rc;
-    if (ctx->pipe_call) { // the next pipelined call's front stage may start now
+    if (ctx->pipe_call && !ctx->pipe_early) { // the next pipelined call's front stage may start now
         VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
         ctx->have_agg_done = true;
     }
@@ -1469,12 +1509,12 @@ static int time_aggregation(vppx_ctx *ctx, int iters, int which, float *ms_out)
     hipEvent_t e0, e1;
     VPPX_HIP(hipEventCreate(&e0));
     VPPX_HIP(hipEventCreate(&e1));
-    const u32 *cr = (const u32 *)ctx->ws[WS_CENSUS_R].p + 512;
+    const u32 *cr = ctx->last_cr;
     const void *vols[8];
     int nvol, eb;
     VPPX_HIP(hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < iters; i++) {
-        rc = run_aggregation(ctx, p, g, (const u8 *)ctx->ws[WS_GRAY_L].p, (const u32 *)ctx->ws[WS_CENSUS_L].p, cr,
+        rc = run_aggregation(ctx, p, g, ctx->last_gl, ctx->last_cl, cr,
                              (const u16 *)ctx->ws[WS_P2LUT].p, maxp2, vols, &nvol, &eb, which);
         if (rc) return rc;
     }

@@ -62,6 +62,9 @@ enum WsSlot {
     WS_GRAY_RV,
     WS_CENSUS_L,
     WS_CENSUS_R,
+    WS_GRAY_L2,      // second set of the images the aggregation reads (pipelined calls alternate: vppx_set_pipeline)
+    WS_CENSUS_L2,
+    WS_CENSUS_R2,
     WS_PATHS,        // 8 per-path L volumes
     WS_S,            // aggregated volume (u16)
     WS_SV,           // per-pass sums of the vertical/diagonal paths (band-marching kernel)
@@ -106,6 +109,8 @@ struct vppx_ctx {
     bool own_stream = false;
     bool legacy_stream = false;    // launches go to the legacy default (null) stream: vppx_set_stream_legacy
     hipStream_t stream2 = nullptr; // side stream: horizontal paths overlap the vertical band launches
+    hipStream_t stream_we = nullptr; // W/E launch of the fused layout when it overlaps the vertical kernel (we_overlap)
+    int we_overlap = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // sub-contexts: the fused batched call splits its frames over `nsub` child contexts (own stream
     // and arena) so that latency-bound stages of one part overlap bandwidth-bound stages of another
@@ -122,6 +127,10 @@ struct vppx_ctx {
     bool front_active = false;     // ctx->stream currently is stream_front
     bool pipe_call = false;        // the running vpp_rsgm call is pipelined (record ev_agg_done after its aggregation)
     bool have_agg_done = false;
+    bool pipe_early = false;       // VPPX_PIPE_EARLY=1 (experiment, measured slower): the next front stage starts next to this call's aggregation instead of next to its sum / WTA
+    int pipe_parity = 0;           // which set of gray / census images the next pipelined call writes
+    const u8 *last_gl = nullptr;   // the images the last call aggregated from (timing helpers)
+    const u32 *last_cl = nullptr, *last_cr = nullptr;
     hipStream_t stream_front = nullptr, main_saved = nullptr;
     hipEvent_t ev_agg_done = nullptr, ev_front_done = nullptr, ev_inputs_auto = nullptr;
     void *inputs_ev = nullptr;     // caller's "inputs of the next call are ready" event (vppx_inputs_ready_event), one-shot
@@ -141,6 +150,7 @@ struct vppx_ctx {
         int timeout_ms = 250;      // bound of one wait for a neighbour (VPPX_V3_TIMEOUT_MS)
         unsigned spin_limit = 0;   // polls per wait, 0 = unbounded (VPPX_V3_SPIN_LIMIT: tests force the give-up path with 1)
         unsigned serial = 0;       // serial of the last fused launch
+        bool ignore_lost = false;  // VPPX_V3_IGNORE_LOST: measurement runs with forced give-ups (results void) carry on
     } v3;
     DevBuf ws[WS_NUM];
     std::string devname;
