@@ -20,15 +20,20 @@ def engines():
     old = os.environ.get("VPPX_VERT")
     try:
         os.environ["VPPX_VERT"] = "3"   # fused whenever the shape allows it
+        os.environ["VPPX_V3_PPW"] = "8"   # ... with the 8-pixels-per-wave kernel at every D
         fused = Engine()
+        os.environ["VPPX_V3_PPW"] = "16"  # ... with the 16-pixels-per-wave kernel at D = 192 (whatever the batch size)
+        wide = Engine()
+        os.environ.pop("VPPX_V3_PPW")
         os.environ["VPPX_VERT"] = "0"   # always the eight line-parallel paths
         eight = Engine()
     finally:
+        os.environ.pop("VPPX_V3_PPW", None)
         if old is None:
             os.environ.pop("VPPX_VERT", None)
         else:
             os.environ["VPPX_VERT"] = old
-    return fused, eight
+    return fused, eight, wide
 
 
 def _case(rng):
@@ -45,7 +50,7 @@ def _case(rng):
 @pytest.mark.parametrize("seed", range(24))
 def test_fused_layout_equals_eight_path_layout(engines, seed):
     import torch
-    fused, eight = engines
+    fused, eight, wide = engines
     rng = np.random.default_rng(1000 + seed)
     B, H, W, kw = _case(rng)
     if seed == 0:
@@ -60,6 +65,11 @@ def test_fused_layout_equals_eight_path_layout(engines, seed):
     torch.cuda.synchronize()
     assert fused.uses_vert() == 3 and eight.uses_vert() == 0, (B, H, W, kw)
     assert torch.equal(out_f, out_8), (B, H, W, kw, int((out_f != out_8).sum()))
+    if kw["dmax"] == 192:   # the 16-pixels-per-wave kernel (sgm_vert4_kernel; the default from 16 frames per call on)
+        out_w = wide.vpp_rsgm(*args, seed=seed, rsgm_kw=kw)
+        wide.synchronize()
+        assert wide.uses_vert() == 3
+        assert torch.equal(out_w, out_8), (B, H, W, kw, int((out_w != out_8).sum()))
     if seed % 5 == 0:   # and against the oracle (frame 0 and the last one)
         got = out_f.cpu().numpy()
         for f in (0, B - 1):
@@ -73,7 +83,7 @@ def test_fused_layout_equals_eight_path_layout(engines, seed):
 def test_fused_layout_wants_byte_sized_three_path_sums(engines):
     """3 * (24 + P2max) > 255: the three-path sum does not fit a byte, the library must stay on the 8-path layout."""
     import torch
-    fused, _ = engines
+    fused, _, _ = engines
     b = synth.make_batch(8, 20, 40, 192, 0.05, seed=3)
     args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(fused.device) for k in ("left", "right", "hints")]
     out = fused.vpp_rsgm(*args, seed=1, rsgm_kw=dict(dmax=192, p2min=17, gamma=62, alpha=0.5))

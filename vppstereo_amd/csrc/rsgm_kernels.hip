@@ -1500,6 +1500,257 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---------------------------------------------------------------------------------------
+// The same fused three-path pass with 16 pixels per wave: 4 lanes x DPL disparities per pixel (round 3; D = 4 * DPL = 192).
+// Everything on gfx950 that this path runs is bound by VALU issue (tools/agg_probe.py: the 8 x 24 kernel takes the same
+// time per frame at 2 waves per SIMD as at 4, and 91 % of its time with every neighbour wait removed), so what counts is
+// instructions per pixel, and those are dominated by what does NOT scale with the disparities a lane holds: the min
+// reduction across a pixel's lanes, the sideways move of the diagonal states, tags, P2 look-ups, addressing.  Twice the
+// disparities per lane halve that share, and the lane layout lane = 16 * chunk + pixel makes the sideways move one
+// DPP row_shr:1 / row_shl:1 per register whose `old` operand IS the neighbour wave's edge record (lane 0 / 15 of a row
+// has no source and keeps it): no ds_bpermute, no select (the 8 x 24 kernel spends 26 + 26 of its 404 instructions per
+// row there, and its LDS crossbar is 35 % busy with them).  What crosses DPP rows is small: the d +- 1 operands at a
+// chunk's ends (2 ds_bpermute per path) and the minimum over the 4 chunks (2 per path).  ~200 VGPRs: 2 waves per SIMD.
+// Edge records, tags, lock step, store transposition: as in sgm_vert3_kernel.
+// ---------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ u32 sgm_update_split_pn(u32 (&L)[NP], const u32 (&C)[NP], u32 P1pk, u32 P2pk, u32 minpk, u32 prev, u32 next)
+{
+    // prev = the pair NP-1 of the lane that holds the next lower disparities (its high half is d = dbase - 1), next = pair 0
+    // of the lane above (its low half is d = dbase + 2 NP); 0x3FFF3FFF where there is none.  Returns the lane's own minimum.
+    const u32 below0 = __builtin_amdgcn_alignbit(L[NP - 1], prev, 16);
+    const u32 above_last = __builtin_amdgcn_alignbit(next, L[0], 16);
+    const u32 t2 = minpk + P2pk;
+    u32 negmin = 0u - minpk;
+    asm volatile("" : "+v"(negmin));
+    u32 m[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_min(i == 0 ? below0 : L[i - 1], i == NP - 1 ? above_last : L[i + 1]);
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] += P1pk;
+#pragma unroll
+    for (int i = 0; i < NP; i++) m[i] = pk_min3_small(m[i], L[i], t2);
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        m[i] = m[i] + C[i] + negmin;
+        L[i] = m[i];
+    }
+#pragma unroll
+    for (int n = NP; n > 1; n = (n + 2) / 3)
+#pragma unroll
+        for (int i = 0; 3 * i < n; i++) {
+            if (3 * i + 2 < n) m[i] = pk_min3_small(m[3 * i], m[3 * i + 1], m[3 * i + 2]);
+            else if (3 * i + 1 < n) m[i] = pk_min(m[3 * i], m[3 * i + 1]);
+            else m[i] = m[3 * i];
+        }
+    return min(m[0] & 0xFFFFu, m[0] >> 16);
+}
+
+template <int DPL>
+__global__ void __launch_bounds__(256, 2) sgm_vert4_kernel(Vert3Args a)
+{
+    constexpr int NP = DPL / 2, D = 4 * DPL, V3_XW = V3Rec<NP>::XW;
+    static_assert(NP % 4 == 0, "edge records are made of 16-byte pieces");
+    static_assert((DPL * 4) % 16 == 0 && DPL % 16 == 0, "a lane's bytes are whole 16-byte pieces");
+    constexpr int TRW = 16 * D / 4; // store transposition words per wave: 16 pixels x D bytes
+    constexpr int NQ = DPL / 16;    // 16-byte pieces of a lane's DPL bytes
+    constexpr u32 NONE = 0x3FFF3FFFu;
+    __shared__ __attribute__((aligned(16))) u32 s_lut[256 + 4 * TRW];
+    __shared__ u32 s_mask[NP * 256]; // [pair][thread]: validity masks of the lanes whose column is below D - 1
+    s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
+    __syncthreads();
+    const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
+    const int group = (jb / a.nbg) * 8 + xcd, bi = jb % a.nbg;
+    const int f = group >> 1, pass = group & 1;
+    const int wv = bi * 4 + (int)(threadIdx.x >> 6);
+    if (wv >= a.nwv) return;
+    const int lane = threadIdx.x & 63, g = lane & 15, lg = lane >> 4;
+    const int x = wv * 16 + g, dbase = DPL * lg;
+    const int Wp = a.Wp, Hp = a.Hp;
+    const size_t fpix = (size_t)f * Hp * Wp;
+    const u8 *gray_f = a.gray + fpix;
+    const u32 *cl_f = a.cl + fpix;
+    const u32 *cr_f = a.cr + fpix;
+    u8 *sv_f = a.sv + (size_t)pass * a.vol_elems + fpix * D;
+    u32 *tr = s_lut + 256 + (threadIdx.x >> 6) * TRW;
+    const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
+    const bool first = lg == 0, last = lg == 3;
+    const bool has_left = wv > 0, has_right = wv + 1 < a.nwv;
+    constexpr int REC = V3_RING * 2 * 4 * V3_XW; // dwords per wave: [row & 3][direction][chunk lane]
+    bool dead = false;
+    u32 *xb_own = a.xbuf + ((size_t)group * a.nwv + wv) * REC;
+    // pixel-0 lanes take the left wave's NW edge (direction 0), pixel-15 lanes the right wave's NE edge (direction 1)
+    const bool edge_lane = (g == 0 && has_left) || (g == 15 && has_right);
+    const int xb_in_off = (int)(((size_t)group * a.nwv + (g == 0 ? (has_left ? wv - 1 : wv) : (has_right ? wv + 1 : wv))) * REC +
+                                ((g == 0 ? 0 : 1) * 4 + lg) * V3_XW) * 4;
+    const int zero_off = (int)((size_t)2 * a.B * a.nwv * REC) * 4; // one record nobody writes
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, zero_off + V3_XW * 4, 0x00020000);
+    const int bp_prev = ((lane - 16) & 63) << 2, bp_next = ((lane + 16) & 63) << 2;
+    const int bp_x16 = (lane ^ 16) << 2, bp_x32 = (lane ^ 32) << 2;
+    const bool masked = wv * 16 < D - 1;
+    if (masked) {
+        const int lim = x - dbase;
+#pragma unroll
+        for (int i = 0; i < NP; i++) s_mask[i * 256 + threadIdx.x] = (i <= lim ? 0xFFFFu : 0u) | (NP + i <= lim ? 0xFFFF0000u : 0u);
+    }
+    u32 inact[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) inact[i] = 0;
+
+    u32 L0[NP], L1[NP], L2[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) L0[i] = L1[i] = L2[i] = 0;
+    u32 mn0 = 0, mn1 = 0, mn2 = 0;
+    u32 prev0 = NONE, next0 = NONE; // the straight path's operands from the neighbouring chunks (fetched a row ahead)
+    int prevI = 0;
+    const int dy = pass == 0 ? 1 : -1;
+    int y = pass == 0 ? 0 : Hp - 1;
+    const int xl = x > 0 ? x - 1 : 0, xr = x < Wp - 1 ? x + 1 : Wp - 1;
+    StepIn<DPL, false> A;
+    load_step<DPL, true, false>(A, gray_f, cl_f, cr_f, nullptr, y * Wp + x, D, dbase, inact);
+    int Ipl = 0, Ipr = 0;
+    u32x4 pend[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) pend[k] = u32x4{0, 0, 0, 0};
+    u32 pend_o = ((u32)(y * Wp + wv * 16) * (u32)D) + (u32)lane * 16u; // harmless first store (rewritten)
+    auto store_pend = [&]() {
+#pragma unroll
+        for (int k = 0; k < NQ; k++) __builtin_nontemporal_store(pend[k], (u32x4 *)(sv_f + pend_o + (u32)k * 1024u));
+    };
+    // minimum over the 4 chunk lanes of a pixel (16 and 32 lanes apart: two DPP rows, two halves of the wave)
+    auto pixel_min = [&](u32 mm) -> u32 {
+        mm = min(mm, (u32)__builtin_amdgcn_ds_bpermute(bp_x16, (int)mm));
+        mm = min(mm, (u32)__builtin_amdgcn_ds_bpermute(bp_x32, (int)mm));
+        return pk_splat(mm);
+    };
+    for (int t = 0; t < Hp; t++, y += dy) {
+        // ---- costs of this row, once for the three paths (pair i of a lane = disparities dbase + i and dbase + NP + i)
+        u32 C[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const u32 c0 = __popc(A.clv ^ A.w[DPL - 1 - i]);
+            const u32 c1 = __popc(A.clv ^ A.w[DPL - 1 - NP - i]);
+            C[i] = (c1 << 16) | c0;
+        }
+        if (masked) {
+            constexpr u32 INVpk = INVALID_DISP_COST | (INVALID_DISP_COST << 16);
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const u32 m = s_mask[i * 256 + threadIdx.x];
+                C[i] = (m & C[i]) | (~m & INVpk);
+            }
+        }
+        const int I = A.I;
+        const u32 P2a = s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)prevI, 0u)];
+        const u32 P2b = s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)Ipl, 0u)];
+        const u32 P2c = s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)Ipr, 0u)];
+        const u32 Tin = (((u32)t & 63u) << 10) | (((u32)t >> 6) << 26);
+        const u32 Tout = (((u32)(t + 1) & 63u) << 10) | (((u32)(t + 1) >> 6) << 26);
+        const int par_in = (t - 1) & (V3_RING - 1), par_out = t & (V3_RING - 1);
+        // ---- the neighbours' edges of the previous row: one round trip to L2, covered by the straight path's update
+        V3Edge<NP> er;
+        const bool want = edge_lane && t > 0;
+        const int eoff = want ? xb_in_off + par_in * (2 * 4 * V3_XW * 4) : zero_off;
+        v3_edges_issue<NP>(xrsrc, eoff, er);
+        // ---- straight path
+        {
+            const u32 mm = sgm_update_split_pn<NP>(L0, C, P1pk, P2a, mn0, prev0, next0);
+            // next row's end operands and this row's minimum: LDS crossbar round trips that nobody waits for before the next row
+            const u32 pv = (u32)__builtin_amdgcn_ds_bpermute(bp_prev, (int)L0[NP - 1]);
+            const u32 nx = (u32)__builtin_amdgcn_ds_bpermute(bp_next, (int)L0[0]);
+            mn0 = pixel_min(mm);
+            prev0 = first ? NONE : pv;
+            next0 = last ? NONE : nx;
+        }
+        v3_edges_complete<NP>(xrsrc, eoff, want, Tin, er, dead, a.timeout_ticks, a.spin_limit);
+        __builtin_amdgcn_s_setprio(2); // from here to the second publish the neighbours wait for this wave
+        u32 prev1, next1, prev2, next2;
+        {
+            u32 e[NP + 1];
+#pragma unroll
+            for (int q = 0; q < NP / 4; q++) {
+                e[4 * q] = er.p[q].x; e[4 * q + 1] = er.p[q].y; e[4 * q + 2] = er.p[q].z; e[4 * q + 3] = er.p[q].w;
+            }
+            e[NP] = er.m;
+            // the two diagonal states move one pixel sideways: DPP inside the 16 pixels of a row of lanes; the lane without a
+            // source (pixel 0 / pixel 15) keeps `old`, which is the record it has just read (zeros where the path restarts).
+            // The registers the chunk-end operands come from move first, so that their crossbar trips overlap the other moves.
+            L1[NP - 1] = dpp_keep<0x111>(e[NP - 1], L1[NP - 1]);
+            L1[0] = dpp_keep<0x111>(e[0], L1[0]);
+            prev1 = (u32)__builtin_amdgcn_ds_bpermute(bp_prev, (int)L1[NP - 1]);
+            next1 = (u32)__builtin_amdgcn_ds_bpermute(bp_next, (int)L1[0]);
+            L2[NP - 1] = dpp_keep<0x101>(e[NP - 1], L2[NP - 1]);
+            L2[0] = dpp_keep<0x101>(e[0], L2[0]);
+            prev2 = (u32)__builtin_amdgcn_ds_bpermute(bp_prev, (int)L2[NP - 1]);
+            next2 = (u32)__builtin_amdgcn_ds_bpermute(bp_next, (int)L2[0]);
+#pragma unroll
+            for (int i = 1; i < NP - 1; i++) {
+                L1[i] = dpp_keep<0x111>(e[i], L1[i]); // row_shr:1 : pixel g takes pixel g - 1
+                L2[i] = dpp_keep<0x101>(e[i], L2[i]); // row_shl:1 : pixel g takes pixel g + 1
+            }
+            mn1 = dpp_keep<0x111>(e[NP], mn1);
+            mn2 = dpp_keep<0x101>(e[NP], mn2);
+            prev1 = first ? NONE : prev1; next1 = last ? NONE : next1;
+            prev2 = first ? NONE : prev2; next2 = last ? NONE : next2;
+        }
+        // ---- last row's bytes
+        store_pend();
+        // ---- NW / SW, then NE / SE; each publishes its edge pixel as soon as it is known
+        {
+            const u32 mm = sgm_update_split_pn<NP>(L1, C, P1pk, P2b, mn1, prev1, next1);
+            mn1 = pixel_min(mm);
+        }
+        if (t + 1 < Hp && g == 15 && has_right) { // the last pixel's state goes to the right wave
+            u32 *q = xb_own + par_out * (2 * 4 * V3_XW) + (0 * 4 + lg) * V3_XW;
+#pragma unroll
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], L1[i + 3] | Tout};
+            q[NP] = mn1 | Tout;
+        }
+        {
+            const u32 mm = sgm_update_split_pn<NP>(L2, C, P1pk, P2c, mn2, prev2, next2);
+            mn2 = pixel_min(mm);
+        }
+        if (t + 1 < Hp && g == 0 && has_left) { // the first pixel's state goes to the left wave
+            u32 *q = xb_own + par_out * (2 * 4 * V3_XW) + (1 * 4 + lg) * V3_XW;
+#pragma unroll
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], L2[i + 3] | Tout};
+            q[NP] = mn2 | Tout;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ---- operands of the next row
+        {
+            const int yn = (t + 1 < Hp) ? y + dy : y;
+            load_step<DPL, true, false>(A, gray_f, cl_f, cr_f, nullptr, yn * Wp + x, D, dbase, inact);
+            Ipl = gray_f[y * Wp + xl];
+            Ipr = gray_f[y * Wp + xr];
+        }
+        // ---- one byte per cell: the three paths summed; a lane's DPL bytes in disparity order = the low halves of its
+        // pairs, then the high halves; transposed through LDS so that every store instruction writes whole lines
+        {
+            u32 tq[NP / 2], bw[NP / 2];
+#pragma unroll
+            for (int k = 0; k < NP / 2; k++) // {lo(2k), lo(2k+1), hi(2k), hi(2k+1)} as bytes
+                tq[k] = __builtin_amdgcn_perm(L0[2 * k + 1] + L1[2 * k + 1] + L2[2 * k + 1], L0[2 * k] + L1[2 * k] + L2[2 * k], 0x06020400u);
+#pragma unroll
+            for (int j = 0; j < NP / 4; j++) {
+                bw[j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x05040100u);
+                bw[NP / 4 + j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x07060302u);
+            }
+            u32x4 *wp = (u32x4 *)(tr + g * (D / 4) + lg * (DPL / 4)); // pixel-major: pixel g, bytes [dbase, dbase + DPL)
+#pragma unroll
+            for (int k = 0; k < NQ; k++) wp[k] = u32x4{bw[4 * k], bw[4 * k + 1], bw[4 * k + 2], bw[4 * k + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < NQ; k++) pend[k] = *(const u32x4 *)(tr + k * 256 + lane * 4);
+            pend_o = (u32)(y * Wp + wv * 16) * (u32)D + (u32)lane * 16u; // the wave's 16 pixels are neighbours in memory
+        }
+        prevI = I;
+    }
+    store_pend();
+    if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The lock-step hand-off goes through ONE L2: all blocks of a (frame, pass) group must run on the same XCD, which the
 // kernel gets from "consecutive block ids go round-robin over the XCDs" (group blocks are 8 ids apart).  Checked once
 // per context on the device it runs on: 256 blocks report the XCD they run on (also true, trivially, when the device is
@@ -1552,6 +1803,14 @@ int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *o
     ctx->v3.blocks_per_cu[1] = v3_blocks_per_cu<16>();
     ctx->v3.blocks_per_cu[2] = v3_blocks_per_cu<24>();
     ctx->v3.blocks_per_cu[3] = v3_blocks_per_cu<32>();
+    {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)sgm_vert4_kernel<48>, 256, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            n = 0;
+        }
+        ctx->v3.blocks_per_cu16 = n;
+    }
     ctx->v3.wall_khz = khz;
     // The kernel decodes (group, block) from blockIdx assuming 8 XCDs that take block ids round-robin.  A single-XCD
     // partition (CPX) passes the pattern test trivially, but there the 8 interleaved groups would have to share the one
@@ -1573,17 +1832,30 @@ bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
 // All blocks of a (frame, pass) group must be resident together, with room to spare for the blocks of the next group
 // that arrive early: at most 3/4 of the block slots of one XCD, counted with what the runtime says about this device
 // and this build (after rsgm_vert3_probe).  Wider frames take the 8-path layout.
-bool rsgm_vert3_fits(const vppx_ctx *ctx, int Wp, int D)
+// D = 192 runs 16 pixels per wave (sgm_vert4_kernel) from 16 frames per launch on: its 15-block groups (960 columns)
+// at 2 blocks per CU need four groups per XCD to fill the chip.  Measured at 540 x 960 x 192, ms per launch 8 / 16 pixels
+// per wave: B = 8 1.00 / 1.18, B = 12 1.34 / 1.58, B = 16 1.79 / 1.61, B = 24 2.99 / 2.94, B = 32 3.85 / 3.27.
+// VPPX_V3_PPW = 8 / 16 forces one of them.
+static bool v3_wide(const vppx_ctx *ctx, int B, int D) { return D == 192 && (ctx->v3.ppw == 16 || (ctx->v3.ppw == 0 && B >= 16)); }
+
+bool rsgm_vert3_fits(const vppx_ctx *ctx, int B, int Wp, int D)
 {
     if (!ctx->v3.ok) return false;
     const int k = D == 64 ? 0 : (D == 128 ? 1 : (D == 192 ? 2 : 3));
-    const int nbg = (Wp / 8 + 3) / 4;
-    return nbg <= ctx->v3.cus_per_xcd * ctx->v3.blocks_per_cu[k] * 3 / 4;
+    const bool wide = v3_wide(ctx, B, D);
+    const int nwv = wide ? Wp / 16 : Wp / 8;
+    const int nbg = (nwv + 3) / 4;
+    const int bpc = wide ? ctx->v3.blocks_per_cu16 : ctx->v3.blocks_per_cu[k];
+    return (!wide || Wp % 16 == 0) && nbg <= ctx->v3.cus_per_xcd * bpc * 3 / 4;
 }
-static int v3_xw(int D) { return D == 256 ? V3Rec<16>::XW : 16; }
+// dwords of edge records per wave: [ring row][direction][lanes per pixel][record slot]
+static int v3_rec_dwords(bool wide, int D) { return wide ? V3_RING * 2 * 4 * V3Rec<24>::XW : V3_RING * 2 * 8 * (D == 256 ? V3Rec<16>::XW : 16); }
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D)
 {
-    return ((size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * v3_xw(D)) + v3_xw(D)) * sizeof(u32); // + the record of zeros
+    // (sized for whichever of the two kernels needs more, + the record of zeros)
+    const size_t narrow = (size_t)2 * B * (Wp / 8) * v3_rec_dwords(false, D);
+    const size_t wide = D == 192 ? (size_t)2 * B * (Wp / 16) * v3_rec_dwords(true, D) : 0;
+    return ((narrow > wide ? narrow : wide) + 32) * sizeof(u32);
 }
 
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
@@ -1593,7 +1865,8 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.xbuf = xbuf; a.err = err;
     a.B = B; a.Hp = Hp; a.Wp = Wp;
     a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (see rsgm_launch_paths); keeps the small-value update in range
-    a.nwv = Wp / 8;
+    const bool wide = v3_wide(ctx, B, D);
+    a.nwv = wide ? Wp / 16 : Wp / 8;
     a.nbg = (a.nwv + 3) / 4;
     a.vol_elems = (size_t)B * Hp * Wp * D;
     a.timeout_ticks = (long long)ctx->v3.timeout_ms * (long long)(ctx->v3.wall_khz > 0 ? ctx->v3.wall_khz : 100000);
@@ -1604,6 +1877,7 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     const dim3 grid((unsigned)(2 * B * a.nbg));
     if (D == 64) sgm_vert3_kernel<8><<<grid, 256, 0, stream>>>(a);
     else if (D == 128) sgm_vert3_kernel<16><<<grid, 256, 0, stream>>>(a);
+    else if (wide) sgm_vert4_kernel<48><<<grid, 256, 0, stream>>>(a);
     else if (D == 192) sgm_vert3_kernel<24><<<grid, 256, 0, stream>>>(a);
     else sgm_vert3_kernel<32><<<grid, 256, 0, stream>>>(a);
     VPPX_CHECK_LAUNCH();

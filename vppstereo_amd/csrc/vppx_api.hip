@@ -180,6 +180,8 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (e) ctx->we_overlap = atoi(e);
         e = getenv("VPPX_V3_TIMEOUT_MS");
         if (e && atoi(e) > 0) ctx->v3.timeout_ms = atoi(e);
+        e = getenv("VPPX_V3_PPW");
+        if (e && (atoi(e) == 8 || atoi(e) == 16)) ctx->v3.ppw = atoi(e);
         e = getenv("VPPX_V3_IGNORE_LOST");
         if (e && atoi(e) > 0) ctx->v3.ignore_lost = true;
         e = getenv("VPPX_V3_SPIN_LIMIT");
@@ -491,7 +493,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         if (!ok) ctx->vert3_broken = true;
     }
     if (!ctx->vert3_probed) v3_ok = false; // (e.g. a first call inside a graph capture takes the 8-path layout)
-    v3_ok = v3_ok && !ctx->vert3_broken && rsgm_vert3_fits(ctx, g.Wp, g.D); // a whole group + early arrivals resident per XCD
+    v3_ok = v3_ok && !ctx->vert3_broken && rsgm_vert3_fits(ctx, g.B, g.Wp, g.D); // a whole group + early arrivals resident per XCD
     // (measured at B=32, 8-path / fused ms per step: D=64 7.5 / 7.5, D=128 10.6 / 9.2, D=192 13.3 / 11.7; 1536x2048x256 at
     // B=8 28.1 / 28.9: the default takes the fused layout for D = 128 and 192)
     const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192)));
