@@ -22,7 +22,7 @@ def engines():
         os.environ["VPPX_VERT"] = "3"   # fused whenever the shape allows it
         os.environ["VPPX_V3_PPW"] = "8"   # ... with the 8-pixels-per-wave kernel at every D
         fused = Engine()
-        os.environ["VPPX_V3_PPW"] = "16"  # ... with the 16-pixels-per-wave kernel at D = 192 (whatever the batch size)
+        os.environ["VPPX_V3_PPW"] = "16"  # ... with the 16-pixels-per-wave kernel (whatever the batch size)
         wide = Engine()
         os.environ.pop("VPPX_V3_PPW")
         os.environ["VPPX_VERT"] = "0"   # always the eight line-parallel paths
@@ -65,11 +65,11 @@ def test_fused_layout_equals_eight_path_layout(engines, seed):
     torch.cuda.synchronize()
     assert fused.uses_vert() == 3 and eight.uses_vert() == 0, (B, H, W, kw)
     assert torch.equal(out_f, out_8), (B, H, W, kw, int((out_f != out_8).sum()))
-    if kw["dmax"] == 192:   # the 16-pixels-per-wave kernel (sgm_vert4_kernel; the default from 16 frames per call on)
-        out_w = wide.vpp_rsgm(*args, seed=seed, rsgm_kw=kw)
-        wide.synchronize()
-        assert wide.uses_vert() == 3
-        assert torch.equal(out_w, out_8), (B, H, W, kw, int((out_w != out_8).sum()))
+    # the 16-pixels-per-wave kernel (sgm_vert4_kernel, every D; the default once a batch fills the chip with its groups)
+    out_w = wide.vpp_rsgm(*args, seed=seed, rsgm_kw=kw)
+    wide.synchronize()
+    assert wide.uses_vert() == 3
+    assert torch.equal(out_w, out_8), (B, H, W, kw, int((out_w != out_8).sum()))
     if seed % 5 == 0:   # and against the oracle (frame 0 and the last one)
         got = out_f.cpu().numpy()
         for f in (0, B - 1):

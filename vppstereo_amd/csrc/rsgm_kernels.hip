@@ -1273,7 +1273,7 @@ __device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int
 
 // dwords per lane of an edge record (NP pairs + the packed minimum, rounded up to whole 64-byte slots)
 template <int NP>
-struct V3Rec { static constexpr int XW = (NP + 1 <= 16) ? 16 : 32; };
+struct V3Rec { static constexpr int XW = (NP + 1 <= 16) ? 16 : (NP + 1 <= 32 ? 32 : 64); };
 
 template <int DPL>
 __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
@@ -1804,12 +1804,16 @@ int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *o
     ctx->v3.blocks_per_cu[2] = v3_blocks_per_cu<24>();
     ctx->v3.blocks_per_cu[3] = v3_blocks_per_cu<32>();
     {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)sgm_vert4_kernel<48>, 256, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            n = 0;
+        const void *wide_fn[4] = {(const void *)sgm_vert4_kernel<16>, (const void *)sgm_vert4_kernel<32>, (const void *)sgm_vert4_kernel<48>,
+                                  (const void *)sgm_vert4_kernel<64>};
+        for (int k = 0; k < 4; k++) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wide_fn[k], 256, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                n = 0;
+            }
+            ctx->v3.blocks_per_cu16[k] = n;
         }
-        ctx->v3.blocks_per_cu16 = n;
     }
     ctx->v3.wall_khz = khz;
     // The kernel decodes (group, block) from blockIdx assuming 8 XCDs that take block ids round-robin.  A single-XCD
@@ -1832,30 +1836,45 @@ bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
 // All blocks of a (frame, pass) group must be resident together, with room to spare for the blocks of the next group
 // that arrive early: at most 3/4 of the block slots of one XCD, counted with what the runtime says about this device
 // and this build (after rsgm_vert3_probe).  Wider frames take the 8-path layout.
-// D = 192 runs 16 pixels per wave (sgm_vert4_kernel) from 16 frames per launch on: its 15-block groups (960 columns)
-// at 2 blocks per CU need four groups per XCD to fill the chip.  Measured at 540 x 960 x 192, ms per launch 8 / 16 pixels
+// 16 pixels per wave (sgm_vert4_kernel) or 8 (sgm_vert3_kernel)?  The wide kernel spends 10-15 % fewer instructions per
+// pixel, but its groups are half as many blocks at half as many blocks per CU: it wins once the groups of a launch fill an
+// XCD's slots at least once.  Measured at 540 x 960 x 192 (15-block groups, 4 per XCD resident), ms per launch 8 / 16 pixels
 // per wave: B = 8 1.00 / 1.18, B = 12 1.34 / 1.58, B = 16 1.79 / 1.61, B = 24 2.99 / 2.94, B = 32 3.85 / 3.27.
 // VPPX_V3_PPW = 8 / 16 forces one of them.
-static bool v3_wide(const vppx_ctx *ctx, int B, int D) { return D == 192 && (ctx->v3.ppw == 16 || (ctx->v3.ppw == 0 && B >= 16)); }
+static int v3_dk(int D) { return D == 64 ? 0 : (D == 128 ? 1 : (D == 192 ? 2 : 3)); }
+static bool v3_wide(const vppx_ctx *ctx, int B, int Wp, int D)
+{
+    if (Wp % 16 != 0 || ctx->v3.ppw == 8) return false;
+    if (ctx->v3.ppw == 16) return true;
+    const int nbg = (Wp / 16 + 3) / 4;
+    const int resident = ctx->v3.cus_per_xcd * ctx->v3.blocks_per_cu16[v3_dk(D)] / (nbg > 0 ? nbg : 1); // whole groups per XCD
+    return resident > 0 && 2 * B / 8 >= resident;
+}
+
+bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D) { return v3_wide(ctx, B, Wp, D); }
 
 bool rsgm_vert3_fits(const vppx_ctx *ctx, int B, int Wp, int D)
 {
     if (!ctx->v3.ok) return false;
-    const int k = D == 64 ? 0 : (D == 128 ? 1 : (D == 192 ? 2 : 3));
-    const bool wide = v3_wide(ctx, B, D);
+    const int k = v3_dk(D);
+    const bool wide = v3_wide(ctx, B, Wp, D);
     const int nwv = wide ? Wp / 16 : Wp / 8;
     const int nbg = (nwv + 3) / 4;
-    const int bpc = wide ? ctx->v3.blocks_per_cu16 : ctx->v3.blocks_per_cu[k];
-    return (!wide || Wp % 16 == 0) && nbg <= ctx->v3.cus_per_xcd * bpc * 3 / 4;
+    const int bpc = wide ? ctx->v3.blocks_per_cu16[k] : ctx->v3.blocks_per_cu[k];
+    return nbg <= ctx->v3.cus_per_xcd * bpc * 3 / 4;
 }
 // dwords of edge records per wave: [ring row][direction][lanes per pixel][record slot]
-static int v3_rec_dwords(bool wide, int D) { return wide ? V3_RING * 2 * 4 * V3Rec<24>::XW : V3_RING * 2 * 8 * (D == 256 ? V3Rec<16>::XW : 16); }
+static int v3_rec_dwords(bool wide, int D)
+{
+    if (!wide) return V3_RING * 2 * 8 * (D == 256 ? V3Rec<16>::XW : 16);
+    return V3_RING * 2 * 4 * (D == 64 ? V3Rec<8>::XW : (D == 128 ? V3Rec<16>::XW : (D == 192 ? V3Rec<24>::XW : V3Rec<32>::XW)));
+}
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D)
 {
     // (sized for whichever of the two kernels needs more, + the record of zeros)
     const size_t narrow = (size_t)2 * B * (Wp / 8) * v3_rec_dwords(false, D);
-    const size_t wide = D == 192 ? (size_t)2 * B * (Wp / 16) * v3_rec_dwords(true, D) : 0;
-    return ((narrow > wide ? narrow : wide) + 32) * sizeof(u32);
+    const size_t wide = (size_t)2 * B * (Wp / 16) * v3_rec_dwords(true, D);
+    return ((narrow > wide ? narrow : wide) + 64) * sizeof(u32);
 }
 
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
@@ -1865,7 +1884,7 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.xbuf = xbuf; a.err = err;
     a.B = B; a.Hp = Hp; a.Wp = Wp;
     a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (see rsgm_launch_paths); keeps the small-value update in range
-    const bool wide = v3_wide(ctx, B, D);
+    const bool wide = v3_wide(ctx, B, Wp, D);
     a.nwv = wide ? Wp / 16 : Wp / 8;
     a.nbg = (a.nwv + 3) / 4;
     a.vol_elems = (size_t)B * Hp * Wp * D;
@@ -1875,9 +1894,12 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     if (a.serial == 0) a.serial = ++ctx->v3.serial;
     VPPX_HIP(hipMemsetAsync(xbuf, 0, rsgm_vert3_xbuf_bytes(B, Wp, D), stream)); // no record of an earlier launch may match
     const dim3 grid((unsigned)(2 * B * a.nbg));
-    if (D == 64) sgm_vert3_kernel<8><<<grid, 256, 0, stream>>>(a);
+    if (wide && D == 64) sgm_vert4_kernel<16><<<grid, 256, 0, stream>>>(a);
+    else if (wide && D == 128) sgm_vert4_kernel<32><<<grid, 256, 0, stream>>>(a);
+    else if (wide && D == 192) sgm_vert4_kernel<48><<<grid, 256, 0, stream>>>(a);
+    else if (wide) sgm_vert4_kernel<64><<<grid, 256, 0, stream>>>(a);
+    else if (D == 64) sgm_vert3_kernel<8><<<grid, 256, 0, stream>>>(a);
     else if (D == 128) sgm_vert3_kernel<16><<<grid, 256, 0, stream>>>(a);
-    else if (wide) sgm_vert4_kernel<48><<<grid, 256, 0, stream>>>(a);
     else if (D == 192) sgm_vert3_kernel<24><<<grid, 256, 0, stream>>>(a);
     else sgm_vert3_kernel<32><<<grid, 256, 0, stream>>>(a);
     VPPX_CHECK_LAUNCH();

@@ -482,7 +482,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     // per launch on (540x960x192, ms per step 8-path / fused: B=4 2.20 / 2.26, B=8 3.74 / 3.27, B=16 6.94 / 5.90,
     // B=32 13.3 / 11.7); a context whose fused launch once lost its lock step never uses it again.
     bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
-    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192)))) {
+    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
         // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes
         // (8 XCDs, round-robin), and how many blocks of this build of the kernel does one XCD hold?
         u32 *probe;
@@ -496,7 +496,11 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     v3_ok = v3_ok && !ctx->vert3_broken && rsgm_vert3_fits(ctx, g.B, g.Wp, g.D); // a whole group + early arrivals resident per XCD
     // (measured at B=32, 8-path / fused ms per step: D=64 7.5 / 7.5, D=128 10.6 / 9.2, D=192 13.3 / 11.7; 1536x2048x256 at
     // B=8 28.1 / 28.9: the default takes the fused layout for D = 128 and 192)
-    const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192)));
+    // Default: the fused layout from 8 frames per launch on for D = 128 / 192, and for every D once the batch fills the chip
+    // with groups of the 16-pixels-per-wave kernel (round 3, ms per step 8-path / fused 8 px per wave / fused 16 px per wave:
+    // 540x960 B=32 D=64 7.4 / 7.5 / 6.8, D=128 10.6 / 9.3 / 9.0; 375x1242x192 B=32 12.1 / 10.4 / 10.2; 1536x2048x256 B=8
+    // 28.7 / 32.0 / 23.1, B=16 56.4 / 64.4 / 46.1)
+    const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192 || rsgm_vert3_wide(ctx, g.B, g.Wp, g.D))));
     const bool vert = vert3 || (ctx->use_vert == 1 && elem_bytes == 1 && rsgm_vert_supported(g.D, maxp2) && g.D <= 192);
     ctx->last_vert = vert3 ? 3 : (vert ? 1 : 0);
     void *paths;

@@ -146,7 +146,7 @@ struct vppx_ctx {
         bool ok = false;
         int nxcd = 0, cus_per_xcd = 0;
         int blocks_per_cu[4] = {0, 0, 0, 0}; // D = 64, 128, 192, 256 (8 pixels per wave)
-        int blocks_per_cu16 = 0;   // D = 192, 16 pixels per wave (sgm_vert4_kernel)
+        int blocks_per_cu16[4] = {0, 0, 0, 0}; // the same for 16 pixels per wave (sgm_vert4_kernel)
         int ppw = 0;               // VPPX_V3_PPW: pixels per wave of the fused kernel at D = 192 (0 = by batch size, 8, 16)
         int wall_khz = 100000;     // rate of s_memrealtime
         int timeout_ms = 250;      // bound of one wait for a neighbour (VPPX_V3_TIMEOUT_MS)
@@ -256,6 +256,7 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
 int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev, bool *ok);
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2);
 bool rsgm_vert3_fits(const vppx_ctx *ctx, int B, int Wp, int D);
+bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err);
