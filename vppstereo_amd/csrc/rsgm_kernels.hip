@@ -127,14 +127,17 @@ __device__ __forceinline__ void load_words_nt(const u32 *p, u32 (&w)[NW])
         w[0] = t.x; w[1] = t.y; w[2] = t.z;
         return;
     }
+    // (4-byte aligned vector types: a lane's chunk starts at a multiple of its own size, e.g. 24 bytes)
+    typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+    typedef u32 u32x2a __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
     for (; i + 4 <= NW; i += 4) {
-        const u32x4 t = __builtin_nontemporal_load((const u32x4 *)(p + i));
+        const u32x4a t = __builtin_nontemporal_load((const u32x4a *)(p + i));
         w[i] = t.x; w[i + 1] = t.y; w[i + 2] = t.z; w[i + 3] = t.w;
     }
 #pragma unroll
     for (; i + 2 <= NW; i += 2) {
-        const u32x2 t = __builtin_nontemporal_load((const u32x2 *)(p + i));
+        const u32x2a t = __builtin_nontemporal_load((const u32x2a *)(p + i));
         w[i] = t.x; w[i + 1] = t.y;
     }
 #pragma unroll
@@ -2018,6 +2021,88 @@ __device__ __forceinline__ float wta_top2(const u32 (&S)[DPL / 2], int dbase, in
     return disp;
 }
 
+// The same decision in two parts (round 3).  Every lane of a pixel ends the reduction with the same (best, second) keys, so
+// whatever follows -- the uniqueness test, the sub-pixel step with its float division, the store -- is the same work done
+// GL times over, and on gfx950 this path is bound by instruction issue.  top2_reduce stops where the lanes agree (and
+// fetches S[best -+ 1], which must be read while the tile is in the ring); the caller lets ONE lane per round keep the
+// result of its pixel and runs top2_final once every GL rounds, for 64 different pixels per wave instruction.
+// GL lanes per pixel (4, 8 or 16), DPL disparities per lane; keys are 16 bits: S << IB | index in the lane.
+struct Top2 {
+    u32 g1, g2, nbv; // value << 8 | disparity of the minimum and of the runner-up; S[best-1] | S[best+1] << 16
+};
+template <int DPL, int GL, typename NB>
+__device__ __forceinline__ Top2 top2_reduce(const u32 (&S)[DPL / 2], int dbase, int n /*valid d: d < n*/, int D, NB nb)
+{
+    constexpr int NP = DPL / 2;
+    constexpr int IB = DPL <= 16 ? 4 : 5; // bits of the index in the lane
+    static_assert(DPL <= 32, "5-bit local index");
+    u32 K[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) K[i] = (S[i] << IB) | (u32)((2 * i) | ((2 * i + 1) << 16));
+    if (__builtin_amdgcn_ballot_w64(n < D) != 0) { // some pixel of this wave has a clipped search range
+        const int c = n - dbase;                   // local indices >= c are not candidates
+#pragma unroll
+        for (int i = 0; i < NP; i++) K[i] |= (2 * i >= c ? 0x0000FFFFu : 0u) | (2 * i + 1 >= c ? 0xFFFF0000u : 0u);
+    }
+    u32 m1 = K[0], m2 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 1; i < NP; i++) {
+        const u16x2 a = __builtin_bit_cast(u16x2, m1), k = __builtin_bit_cast(u16x2, K[i]);
+        const u32 t = __builtin_bit_cast(u32, __builtin_elementwise_max(a, k));
+        m1 = pk_min(m1, K[i]);
+        m2 = pk_min(m2, t);
+    }
+    const u32 a1 = m1 & 0xFFFFu, b1 = m1 >> 16, a2 = m2 & 0xFFFFu, b2 = m2 >> 16;
+    const u32 k1 = min(a1, b1), k2 = min(max(a1, b1), min(a2, b2));
+    // 32-bit keys comparable across the pixel's lanes: value << 8 | disparity (first minimum wins on ties); a masked key
+    // keeps the largest value 16 - IB bits hold
+    u32 g1 = ((k1 >> IB) << 8) | (u32)(dbase + (int)(k1 & ((1u << IB) - 1u)));
+    u32 g2 = ((k2 >> IB) << 8) | (u32)(dbase + (int)(k2 & ((1u << IB) - 1u)));
+#define VPPX_TOP2_STEP(CTRL)                                    \
+    {                                                           \
+        const u32 p1 = dpp_ror<CTRL>(g1), p2 = dpp_ror<CTRL>(g2); \
+        const u32 t = max(g1, p1);                              \
+        g1 = min(g1, p1);                                       \
+        g2 = min(min(g2, p2), t);                               \
+    }
+    if constexpr (GL == 16) {
+        VPPX_TOP2_STEP(0x128) VPPX_TOP2_STEP(0x124) VPPX_TOP2_STEP(0x122) VPPX_TOP2_STEP(0x121)
+    } else { // partners l ^ 1, l ^ 2 (quad permutations), then 7 - l (row_half_mirror): disjoint sets at every step
+        VPPX_TOP2_STEP(0xB1) VPPX_TOP2_STEP(0x4E)
+        if constexpr (GL == 8) VPPX_TOP2_STEP(0x141)
+    }
+#undef VPPX_TOP2_STEP
+    const int best = (int)(g1 & 0xFFu);
+    const u32 cm1 = best >= 1 ? nb(best - 1) : 0u, cp1 = best + 1 < D ? nb(best + 1) : 0u;
+    Top2 r;
+    r.g1 = g1;
+    r.g2 = g2;
+    r.nbv = cm1 | (cp1 << 16);
+    return r;
+}
+template <int DPL>
+__device__ __forceinline__ float top2_final(u32 g1, u32 g2, u32 nbv, int n, int D, u32 factor_uniq, bool do_subpixel, bool x_interior)
+{
+    constexpr int IB = DPL <= 16 ? 4 : 5;
+    const int best = (int)(g1 & 0xFFu);
+    const u32 minc = g1 >> 8;
+    u32 sec = g2 >> 8;
+    sec = sec >= (0xFFFFu >> IB) ? 65535u : sec; // masked keys: no second candidate
+    const u32 cm1 = nbv & 0xFFFFu, cp1 = nbv >> 16;
+    bool ok = (1024u * minc <= sec * factor_uniq);
+    if (!ok) {
+        if (best > 0 && cm1 == sec) ok = true;
+        if (best + 1 < n && cp1 == sec) ok = true;
+    }
+    float disp = ok ? (float)best : INVALID_DISP;
+    if (do_subpixel && x_interior && disp > 0.0f && best >= 1 && best <= D - 2) {
+        const int c0 = (int)cm1, c1 = (int)minc, c2 = (int)cp1;
+        const int den = (c2 < c0) ? c0 - c1 : c2 - c1;
+        if (den != 0) disp = (float)best + __fdiv_rn((float)(c0 - c2), __fmul_rn(2.0f, (float)den));
+    }
+    return disp;
+}
+
 // A block owns 64 consecutive pixels of one row (4 rounds of 16 pixels).  Besides the left
 // disparity it writes the aggregated volume in one or both of two layouts:
 //   S  [y][x][d]  ("xyd", the reference's dsiAgg layout; stage API only)
@@ -2153,13 +2238,17 @@ struct VolPtrs {
 // across row boundaries, so the fill/drain rounds are paid once per block instead of once per row.
 // SW4: byte volumes whose values are <= 63 (4 * max <= 255): four volumes are added as packed bytes with plain
 // 32-bit adds (no carry can cross a byte) before the sums are widened to u16 pairs
-template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false>
-__global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
+// GL = lanes per pixel (16; 8 for the byte volumes of D = 128 / 192, round 3: per-pixel overhead -- cross-lane merges, ring
+// addressing, cursors -- is paid per lane, and the kernel is bound by instruction issue).  FAST variants finalise a pixel
+// once, not GL times (top2_reduce / top2_final): a lane keeps the keys of ONE pixel per GL rounds.
+template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false, int GL = 16>
+__global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
                                                           float *__restrict__ disp_r, int Hp, int Wp, u32 factor_uniq,
                                                           int do_subpixel, int rows_per_block)
 {
     constexpr int NP = DPL / 2;
-    constexpr int D = 16 * DPL;
+    constexpr int D = GL * DPL;
+    static_assert(GL == 16 || FAST, "fewer lanes per pixel: byte-volume variants only");
     constexpr int NR = (T + D - 2) / T + 1; // tiles a right pixel can touch (x .. x+D-1)
     constexpr int NT = NR + (SPARE ? 1 : 0);
     constexpr int TW = T + 2;               // tile row pitch in u16 (2 pad)
@@ -2171,8 +2260,23 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
     const int r0 = blockIdx.x * rows_per_block;
     const int nrows = (Hp - r0 < rows_per_block) ? Hp - r0 : rows_per_block;
     const size_t framepix = (size_t)f * Hp * Wp;
-    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int g = threadIdx.x / GL, l16 = threadIdx.x % GL; // pixel of the round, lane of the pixel
     const int dbase = DPL * l16;
+    // deferred finalisation (FAST): the keys of the pixel this lane keeps, per view {g1, g2, S[best-+1], n | interior << 9 |
+    // valid << 10, pixel index in the frame}
+    u32 kl[5] = {0, 0, 0, 0, 0}, kr[5] = {0, 0, 0, 0, 0};
+    auto flush = [&]() {
+        if (kl[3]) {
+            const float dv = top2_final<DPL>(kl[0], kl[1], kl[2], (int)(kl[3] & 511u), D, factor_uniq, do_subpixel != 0, (kl[3] >> 9) & 1u);
+            disp_l[framepix + kl[4]] = dv;
+        }
+        if (kr[3]) {
+            const float dv = top2_final<DPL>(kr[0], kr[1], kr[2], (int)(kr[3] & 511u), D, factor_uniq, false, false);
+            disp_r[framepix + kr[4]] = dv;
+        }
+        kl[3] = 0;
+        kr[3] = 0;
+    };
     const int ntiles = (Wp + T - 1) / T;
     const int total = nrows * ntiles;
     // stream cursors (uniform): fetch runs two rounds ahead of the left view, the right view NR-1 behind
@@ -2251,14 +2355,18 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
                     t[(dbase + 2 * i + 1) * TW] = (u16)(acc[i] >> 16);
                 }
                 const int n = (x < D - 1 ? x : D - 1) + 1;
-                float dv;
                 if constexpr (FAST) { // the pixel's column was just written by this wave (LDS keeps a wave's accesses in order)
-                    dv = wta_top2<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2,
-                                       [&](int d) -> u32 { return t[d * TW]; });
+                    const Top2 r = top2_reduce<DPL, GL>(acc, dbase, n, D, [&](int d) -> u32 { return t[d * TW]; });
+                    if (l16 == (j & (GL - 1))) { // this lane keeps this round's pixel
+                        asm volatile("; keep (left view)");
+                        kl[0] = r.g1; kl[1] = r.g2; kl[2] = r.nbv;
+                        kl[3] = (u32)n | ((x >= 1 && x <= Wp - 2) ? 512u : 0u) | 1024u;
+                        kl[4] = (u32)(l_row * Wp + x);
+                    }
                 } else {
-                    dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
+                    const float dv = wta_rows<DPL>(acc, dbase, n, D, factor_uniq, do_subpixel != 0, x >= 1 && x <= Wp - 2);
+                    if (l16 == 0) disp_l[framepix + (size_t)l_row * Wp + x] = dv;
                 }
-                if (l16 == 0) disp_l[framepix + (size_t)l_row * Wp + x] = dv;
             }
             l_slot = (l_slot + 1 == NT) ? 0 : l_slot + 1;
             if (++l_k == ntiles) {
@@ -2303,24 +2411,32 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
                     const u32 hi = ring[s1 * TS + (dbase + 2 * i + 1) * TW + (a1 % T)];
                     sr[i] = lo | (hi << 16);
                 }
-                float dv;
                 if constexpr (FAST) {
-                    dv = wta_top2<DPL>(sr, dbase, n, D, factor_uniq, false, false, [&](int d) -> u32 {
+                    const Top2 r = top2_reduce<DPL, GL>(sr, dbase, n, D, [&](int d) -> u32 {
                         const u32 a = (u32)(g + d);
                         u32 sl = r_slot + a / T;
                         sl = sl >= NT ? sl - NT : sl;
                         return ring[sl * TS + d * TW + (a % T)];
                     });
+                    if (l16 == (j & (GL - 1))) {
+                        asm volatile("; keep (right view)");
+                        kr[0] = r.g1; kr[1] = r.g2; kr[2] = r.nbv;
+                        kr[3] = (u32)n | 1024u;
+                        kr[4] = (u32)(r_row * Wp + xr);
+                    }
                 } else {
-                    dv = wta_rows<DPL>(sr, dbase, n, D, factor_uniq, false, false);
+                    const float dv = wta_rows<DPL>(sr, dbase, n, D, factor_uniq, false, false);
+                    if (l16 == 0) disp_r[framepix + (size_t)r_row * Wp + xr] = dv;
                 }
-                if (l16 == 0) disp_r[framepix + (size_t)r_row * Wp + xr] = dv;
             }
             r_slot = (r_slot + 1 == NT) ? 0 : r_slot + 1;
             if (++r_k == ntiles) {
                 r_k = 0;
                 r_row++;
             }
+        }
+        if constexpr (FAST) {
+            if ((j & (GL - 1)) == GL - 1) flush(); // every lane of the wave holds a pixel of its own now
         }
         if (!SPARE) __syncthreads();
     };
@@ -2339,19 +2455,20 @@ __global__ void __launch_bounds__(16 * T) sum_wta_lr_kernel(VolPtrs vols, float 
             if (j + 1 < total + NR - 1) round(j + 1, wb);
         }
     }
+    if constexpr (FAST) flush();
 }
 
-template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false>
+template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false, int GL = 16>
 static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
 {
-    constexpr int D = 16 * DPL;
+    constexpr int D = GL * DPL;
     constexpr int NR = (T + D - 2) / T + 1;
     constexpr int NT = NR + (SPARE ? 1 : 0);
     const size_t lds = ((size_t)NT * D * (T + 2) + T) * sizeof(u16);
     static bool attr_set[VPPX_MAX_DEVICES] = {}; // function attributes are per device
     const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
     if (!attr_set[dv]) {
-        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST>,
+        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST, GL>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dv] = true;
     }
@@ -2381,7 +2498,7 @@ static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp,
     }
     const int rpb = (Hp + chunks - 1) / chunks;
     chunks = (Hp + rpb - 1) / rpb;
-    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST><<<dim3(chunks, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
+    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST, GL><<<dim3(chunks, B), GL * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
     VPPX_CHECK_LAUNCH();
     return 0;
 }
@@ -2392,6 +2509,13 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
 {
     if constexpr (sizeof(IT) == 1) {
         static const int fast = getenv("VPPX_SUM_FAST") ? atoi(getenv("VPPX_SUM_FAST")) : 1;
+        // VPPX_SUM_GL=8 (experiment): 8 lanes per pixel with twice the disparities per lane for D = 128 / 192.  A fifth fewer
+        // instructions, but one 512-thread block per CU (the LDS ring) is 2 waves per SIMD between two block-wide barriers
+        // per round: 2.89 ms per B=32 launch against 2.44 with 16 lanes per pixel (4 waves per SIMD).  Bit-exact all the same.
+        static const int gl = getenv("VPPX_SUM_GL") ? atoi(getenv("VPPX_SUM_GL")) : 16;
+        if constexpr (DPL == 8 || DPL == 12) {
+            if (sw4 && fast && gl == 8) return launch_lr_t2<2 * DPL, IT, NV, T, SPARE, true, true, 8>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+        }
         if (sw4 && fast) return launch_lr_t2<DPL, IT, NV, T, SPARE, true, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
         if (sw4) return launch_lr_t2<DPL, IT, NV, T, SPARE, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
     }

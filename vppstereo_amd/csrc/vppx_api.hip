@@ -175,7 +175,7 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         // bounds of one neighbour wait in the fused aggregation kernel: milliseconds of wall clock (the bound that counts)
         // and, for tests that must see the give-up path, a number of polls (1 = give up at the first record not there yet)
         e = getenv("VPPX_PIPE_EARLY");
-        if (e) ctx->pipe_early = atoi(e) != 0;
+        if (e) ctx->pipe_early = atoi(e);
         e = getenv("VPPX_WE_OVERLAP");
         if (e) ctx->we_overlap = atoi(e);
         e = getenv("VPPX_V3_TIMEOUT_MS");
@@ -561,6 +561,10 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         } else if (which == 0 && vert3) {
             // one after the other: both launches fill the chip, two streams only interleave them (measured: no gain)
             if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11))) return rc;
+            if (ctx->pipe_call && ctx->pipe_early == 2) { // experiment: the next front stage starts next to the fused vertical kernel
+                VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
+                ctx->have_agg_done = true;
+            }
             if ((rc = launch_vert(ctx->stream))) return rc;
         } else if (which == 0) {
             VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -662,7 +666,7 @@ static int front_end(vppx_ctx *ctx)
     for (int i = 0; i < ctx->n_pipe_copy; i++)
         VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_pipe_copy = 0;
-    if (ctx->pipe_call && ctx->pipe_early) {
+    if (ctx->pipe_call && ctx->pipe_early == 1) {
         // From here on nothing of this call reads what a front stage writes, except the gray / census images the
         // aggregation takes -- and those alternate between two sets by call parity.  The NEXT call's front stage may
         // therefore start now, next to this call's aggregation (it fills the sparsely occupied second round of the W/E

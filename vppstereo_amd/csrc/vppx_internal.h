@@ -127,7 +127,7 @@ struct vppx_ctx {
     bool front_active = false;     // ctx->stream currently is stream_front
     bool pipe_call = false;        // the running vpp_rsgm call is pipelined (record ev_agg_done after its aggregation)
     bool have_agg_done = false;
-    bool pipe_early = false;       // VPPX_PIPE_EARLY=1 (experiment, measured slower): the next front stage starts next to this call's aggregation instead of next to its sum / WTA
+    int pipe_early = 0;           // VPPX_PIPE_EARLY=1 (experiment, measured slower): the next front stage starts next to this call's aggregation instead of next to its sum / WTA
     int pipe_parity = 0;           // which set of gray / census images the next pipelined call writes
     const u8 *last_gl = nullptr;   // the images the last call aggregated from (timing helpers)
     const u32 *last_cl = nullptr, *last_cr = nullptr;
