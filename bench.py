@@ -533,7 +533,8 @@ def run_rank(args):
         cells_launch = agg_frames * Hp * Wp * D
         # SURVEY 8d prices the 8-path aggregation at 10 B/cell; the fused vertical kernel carries 6 of the 8 paths
         agg_bytes = AGG_BYTES_PER_CELL * (6.0 / 8.0 if fused else 1.0)
-        dom_kernel = "sgm_vert3_kernel" if fused else "sgm_paths_kernel"
+        wide = fused and eng.fused_pixels_per_wave() == 16
+        dom_kernel = ("sgm_vert4_kernel" if wide else "sgm_vert3_kernel") if fused else "sgm_paths_kernel"
         achieved = cells_launch * agg_bytes / (agg_ms * 1e-3) / 1e9
         pmc = pmc_view(agg_frames, agg_ms, dom_kernel)
         we_ms = eng.time_aggregate_part(1, 3) if fused else None
@@ -581,8 +582,8 @@ def run_rank(args):
                         "wave_cycles_active_issuewait_memwait": [pmc.get("sq_active_inst_any_frac_of_wave_cycles"),
                                                                  pmc.get("sq_wait_inst_any_frac_of_wave_cycles"),
                                                                  pmc.get("sq_wait_any_frac_of_wave_cycles")]}
-        dom = {"kernel": ("sgm_vert3_kernel (N, NW, NE and S, SW, SE fused three at a time: 6 of the 8 aggregation paths)"
-                          if fused else "sgm_paths_kernel (8-path aggregation)"),
+        dom = {"kernel": (f"{dom_kernel} (N, NW, NE and S, SW, SE fused three at a time: 6 of the 8 aggregation paths; "
+                          f"{16 if wide else 8} pixels per wave)" if fused else "sgm_paths_kernel (8-path aggregation)"),
                "bound": "valu",
                "kernel_ms": round(agg_ms, 4), "kernel_launches_timed": agg_n, "kernel_ms_back_to_back": round(agg_ms_b2b, 4),
                "share_of_step": round(agg_ms / ms_per_step, 3),

@@ -323,6 +323,10 @@ int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, float *ms_out);
  * frames per call on; environment VPPX_VERT = 0 / 3 forces a layout), 1 = the round-1 band-marching experiment
  * (VPPX_VERT = 1).  All layouts give identical results. */
 int vppx_uses_vert(vppx_ctx *ctx);
+/* Which fused kernel the last call used: 16 = sgm_vert4_kernel (16 pixels per wave, 4 lanes per pixel: the default once a
+ * batch fills the chip with its groups), 8 = sgm_vert3_kernel (8 lanes per pixel; VPPX_V3_PPW = 8 / 16 forces one),
+ * 0 = the last call did not use the fused layout. */
+int vppx_fused_pixels_per_wave(vppx_ctx *ctx);
 /* Per-stage hipEvent timing of the last vppx_vpp_rsgm_dev/vppx_rsgm_dev call when stage
  * timing is enabled: fills ms[0..n) and returns the number of stages; names via
  * vppx_stage_name(i). */

@@ -1888,6 +1888,7 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     a.B = B; a.Hp = Hp; a.Wp = Wp;
     a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (see rsgm_launch_paths); keeps the small-value update in range
     const bool wide = v3_wide(ctx, B, Wp, D);
+    ctx->v3.last_ppw = wide ? 16 : 8;
     a.nwv = wide ? Wp / 16 : Wp / 8;
     a.nbg = (a.nwv + 3) / 4;
     a.vol_elems = (size_t)B * Hp * Wp * D;
@@ -2956,11 +2957,27 @@ __device__ __forceinline__ int uf_find(int *label, int i)
     }
     return i;
 }
+// the same with path halving, for the union pass: most of a frame is ONE component (neighbouring disparities differ by
+// less than maxDiff almost everywhere), so without it every union walks the chain of that component's runs.  A label
+// only ever decreases, and whoever lowers a non-root label with atomicMin goes on to unite the parent it displaced
+// (uf_union), so shortcutting i to its grandparent -- with atomicMin as well: never undoes a lower label set meanwhile --
+// keeps every pixel in its component.
+__device__ __forceinline__ int uf_find_halve(int *label, int i)
+{
+    int p = label[i];
+    while (p != i) {
+        const int gp = label[p];
+        if (gp != p) atomicMin(&label[i], gp);
+        i = p;
+        p = gp;
+    }
+    return i;
+}
 __device__ __forceinline__ void uf_union(int *label, int a, int b)
 {
     while (true) {
-        a = uf_find(label, a);
-        b = uf_find(label, b);
+        a = uf_find_halve(label, a);
+        b = uf_find_halve(label, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; } // a > b : hang a under b
         const int old = atomicMin(&label[a], b);
@@ -3154,26 +3171,32 @@ __global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__
 }
 // columns (rsgm.py:216-227): per column, rows above the first valid row take its value, rows
 // below the last valid row take that one's.  Block = 64 columns x 4 row-lanes.
-__global__ void __launch_bounds__(256) interp_bg_cols_kernel(float *__restrict__ dm, int H, int W)
+#define BGC_RL 16 // row lanes per column (a block is 64 columns wide: few blocks per frame, so each gets many rows in flight)
+__global__ void __launch_bounds__(64 * BGC_RL) interp_bg_cols_kernel(float *__restrict__ dm, int H, int W)
 {
-    __shared__ int s_first[4][64], s_last[4][64];
+    __shared__ int s_first[BGC_RL][64], s_last[BGC_RL][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int u = blockIdx.x * 64 + cx;
     const int f = blockIdx.y;
     float *g = dm + (size_t)f * H * W;
     int first = 0x7FFFFFFF, last = -1;
     if (u < W)
-        for (int v = ry; v < H; v += 4)
+        for (int v = ry; v < H; v += BGC_RL)
             if (g[(size_t)v * W + u] > 0) { first = min(first, v); last = max(last, v); }
     s_first[ry][cx] = first;
     s_last[ry][cx] = last;
     __syncthreads();
-    first = min(min(s_first[0][cx], s_first[1][cx]), min(s_first[2][cx], s_first[3][cx]));
-    last = max(max(s_last[0][cx], s_last[1][cx]), max(s_last[2][cx], s_last[3][cx]));
+    first = 0x7FFFFFFF;
+    last = -1;
+#pragma unroll
+    for (int k = 0; k < BGC_RL; k++) {
+        first = min(first, s_first[k][cx]);
+        last = max(last, s_last[k][cx]);
+    }
     if (u >= W || last < 0) return;
     const float fv = g[(size_t)first * W + u], lv = g[(size_t)last * W + u];
-    for (int v = ry; v < first; v += 4) g[(size_t)v * W + u] = fv;
-    for (int v = last + 1 + ry; v < H; v += 4) g[(size_t)v * W + u] = lv;
+    for (int v = ry; v < first; v += BGC_RL) g[(size_t)v * W + u] = fv;
+    for (int v = last + 1 + ry; v < H; v += BGC_RL) g[(size_t)v * W + u] = lv;
 }
 
 int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
@@ -3198,7 +3221,7 @@ int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, cons
     if (g.W <= 2048) interp_bg_rows_kernel<8><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
     else interp_bg_rows_kernel<32><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();
-    interp_bg_cols_kernel<<<dim3((g.W + 63) / 64, g.B), 256, 0, ctx->stream>>>(out, g.H, g.W);
+    interp_bg_cols_kernel<<<dim3((g.W + 63) / 64, g.B), 64 * BGC_RL, 0, ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();
     return 0;
 }

@@ -322,6 +322,7 @@ extern "C" int vppx_status(vppx_ctx *ctx)
 }
 
 extern "C" long vppx_lockstep_failures(vppx_ctx *ctx) { return ctx ? ctx->lockstep_failures : 0; }
+extern "C" int vppx_fused_pixels_per_wave(vppx_ctx *ctx) { return (ctx && ctx->last_vert == 3) ? ctx->v3.last_ppw : 0; }
 
 extern "C" size_t vppx_workspace_bytes(const vppx_ctx *ctx)
 {

@@ -152,6 +152,7 @@ struct vppx_ctx {
         int timeout_ms = 250;      // bound of one wait for a neighbour (VPPX_V3_TIMEOUT_MS)
         unsigned spin_limit = 0;   // polls per wait, 0 = unbounded (VPPX_V3_SPIN_LIMIT: tests force the give-up path with 1)
         unsigned serial = 0;       // serial of the last fused launch
+        int last_ppw = 0;          // pixels per wave of the last fused launch (8: sgm_vert3_kernel, 16: sgm_vert4_kernel)
         bool ignore_lost = false;  // VPPX_V3_IGNORE_LOST: measurement runs with forced give-ups (results void) carry on
     } v3;
     DevBuf ws[WS_NUM];
