@@ -174,6 +174,8 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
         // bounds of one neighbour wait in the fused aggregation kernel: milliseconds of wall clock (the bound that counts)
         // and, for tests that must see the give-up path, a number of polls (1 = give up at the first record not there yet)
+        e = getenv("VPPX_WE4");
+        if (e) ctx->we4 = atoi(e);
         e = getenv("VPPX_PIPE_EARLY");
         if (e) ctx->pipe_early = atoi(e);
         e = getenv("VPPX_WE_OVERLAP");
@@ -514,6 +516,14 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         if ((rc = ws_get(ctx, WS_SV, ncell * 2, &sv))) return rc;
         if ((rc = ws_get(ctx, WS_VSTATE, vert3 ? rsgm_vert3_xbuf_bytes(g.B, g.Wp, g.D) : rsgm_vert_state_bytes(g.B, g.Wp, g.D), &gst))) return rc;
         if ((rc = ws_get(ctx, WS_VMIN, vert3 ? 8 : rsgm_vert_min_elems(g.B, g.Wp), &gmin))) return rc;
+        // W and E: 16 rows per wave (sgm_horiz4_kernel) next to the fused vertical kernels; VPPX_WE4=0 keeps the line kernel
+        auto launch_we = [&]() -> int {
+            if (vert3 && ctx->we4 == 8 && rsgm_horiz4_supported(g.Hp, g.Wp, g.D))
+                return rsgm_launch_horiz8(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, paths);
+            if (vert3 && ctx->we4 == 4 && rsgm_horiz4_supported(g.Hp, g.Wp, g.D))
+                return rsgm_launch_horiz4(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, paths);
+            return rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11);
+        };
         auto launch_vert = [&](hipStream_t st) -> int {
             if (!vert3) return rsgm_launch_vert(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, gst, gmin);
             if (!ctx->vert3_err) { // the word a wave that gives up reports through: no fused launch without it
@@ -553,7 +563,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             VPPX_HIP(hipStreamWaitEvent(ctx->stream_we, ctx->ev_fork, 0));
             hipStream_t main_stream = ctx->stream;
             ctx->stream = ctx->stream_we;
-            rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11);
+            rc = launch_we();
             ctx->stream = main_stream;
             if (rc) return rc;
             VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream_we));
@@ -561,7 +571,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         } else if (which == 0 && vert3) {
             // one after the other: both launches fill the chip, two streams only interleave them (measured: no gain)
-            if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11))) return rc;
+            if ((rc = launch_we())) return rc;
             if (ctx->pipe_call && ctx->pipe_early == 2) { // experiment: the next front stage starts next to the fused vertical kernel
                 VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
                 ctx->have_agg_done = true;
@@ -579,7 +589,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             if ((rc = launch_vert(ctx->stream))) return rc;
             VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         } else if (which == 1) {
-            if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11))) return rc;
+            if ((rc = launch_we())) return rc;
         } else {
             if ((rc = launch_vert(ctx->stream))) return rc;
         }
@@ -707,7 +717,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_GRAY_LV, npp, &glv))) return rc;
     if ((rc = ws_get(ctx, WS_GRAY_RV, npp, &grv))) return rc;
     if ((rc = ws_get(ctx, alt ? WS_CENSUS_L2 : WS_CENSUS_L, npp, &cl))) return rc;
-    if ((rc = ws_get(ctx, alt ? WS_CENSUS_R2 : WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
+    if ((rc = ws_get(ctx, alt ? WS_CENSUS_R2 : WS_CENSUS_R, npp + 512 + 64, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads), 64 behind (sgm_horiz4_kernel loads its window a group of four columns ahead)
     u32 *cr = cr_raw + 512;
     ctx->last_gl = gl; ctx->last_cl = cl; ctx->last_cr = cr;
     {

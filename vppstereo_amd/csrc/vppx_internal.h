@@ -111,6 +111,7 @@ struct vppx_ctx {
     hipStream_t stream2 = nullptr; // side stream: horizontal paths overlap the vertical band launches
     hipStream_t stream_we = nullptr; // W/E launch of the fused layout when it overlaps the vertical kernel (we_overlap)
     int we_overlap = 0;
+    int we4 = 8;                     // W/E of the fused layout: 8 = sgm_horiz8_kernel, 4 = sgm_horiz4_kernel, 0 = the line-parallel kernel (VPPX_WE4)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // sub-contexts: the fused batched call splits its frames over `nsub` child contexts (own stream
     // and arena) so that latency-bound stages of one part overlap bandwidth-bound stages of another
@@ -261,6 +262,11 @@ bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err);
+bool rsgm_horiz4_supported(int Hp, int Wp, int D);
+int rsgm_launch_horiz4(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut,
+                       int p1, void *paths);
+int rsgm_launch_horiz8(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut,
+                       int p1, void *paths);
 bool rsgm_vert_supported(int D, int maxp2);
 size_t rsgm_vert_state_bytes(int B, int Wp, int D);
 size_t rsgm_vert_min_elems(int B, int Wp);
