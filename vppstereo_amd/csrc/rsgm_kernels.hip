@@ -1754,387 +1754,6 @@ __global__ void __launch_bounds__(256, 2) sgm_vert4_kernel(Vert3Args a)
     if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// ---------------------------------------------------------------------------------------
-// W and E of the fused layout with 16 ROWS per wave (round 3): the lane layout of sgm_vert4_kernel turned by 90 degrees.
-// lane = 16 * chunk + row: 4 lanes x DPL disparities per pixel, a wave walks 16 neighbouring rows of one frame in x.  The
-// horizontal path is this layout's "straight" path: its state never leaves the lane, there is no hand-off and no lock step.
-// Against sgm_paths_kernel<16, 12> (16 lanes x 12 disparities, 4 rows per wave) the per-pixel overhead -- minimum over the
-// pixel's lanes, P2 look-up, addressing, the d +- 1 operands at the lane ends -- is spread over four times the
-// disparities, and the right-image census window lives in registers: moving one pixel shifts it by one word, so the wave
-// loads 4 new words per lane every 4 steps (phase p of a group of four steps reads the window at offset p) instead of the
-// whole window every step.  Bytes leave two pixels at a time (2 * D bytes = whole 128-byte lines per row) through an LDS
-// transposition, as everywhere.  ~19 instructions per pixel instead of 26.
-// ---------------------------------------------------------------------------------------
-struct Horiz4Args {
-    const u8 *gray;
-    const u32 *cl;
-    const u32 *cr;
-    const u16 *p2lut;
-    u8 *out; // [2 directions][B][Hp][Wp][D]: W, then E
-    int B, Hp, Wp, p1;
-    size_t vol_elems;
-};
-
-template <int DPL, bool EAST>
-__device__ __forceinline__ void horiz4_walk(const Horiz4Args &a, const u32 *s_lut, u32 *tr, const u8 *gray_r, const u32 *cl_r,
-                                            const u32 *cr_r, u8 *out_f, int y0, int lane)
-{
-    constexpr int NP = DPL / 2, D = 4 * DPL, NQ = DPL / 16, NST = D / 32; // NST = store instructions per two pixels
-    constexpr int TRH = 32 * D / 4;                                          // words of one tile buffer
-    constexpr u32 NONE = 0x3FFF3FFFu;
-    const int g = lane & 15, lg = lane >> 4;
-    const int dbase = DPL * lg, Wp = a.Wp;
-    const bool first = lg == 0, last = lg == 3;
-    const int bp_prev = ((lane - 16) & 63) << 2, bp_next = ((lane + 16) & 63) << 2;
-    const int bp_x16 = (lane ^ 16) << 2, bp_x32 = (lane ^ 32) << 2;
-    const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
-    u32 L[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) L[i] = 0;
-    u32 minpk = 0, prev = NONE, next = NONE;
-    // the census window: ww[j] = cr[xg - dbase - (DPL - 1) + j] (W: xg = first column of the group of 4) or
-    // cr[xg - 3 - dbase - (DPL - 1) + j] (E: xg = last column of the group, walked downwards)
-    u32 ww[DPL + 4];
-    const int xg0 = EAST ? Wp - 1 : 0;
-    {
-        const u32 *wp = cr_r + (xg0 - (EAST ? 3 : 0) - dbase - (DPL - 1));
-#pragma unroll
-        for (int q = 0; q < (DPL + 4) / 4; q++) {
-            struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
-            const u32x4 t = ((const V4 *)(wp + 4 * q))->v;
-            ww[4 * q] = t.x; ww[4 * q + 1] = t.y; ww[4 * q + 2] = t.z; ww[4 * q + 3] = t.w;
-        }
-    }
-    int prevI = -1;
-    bool have_pair = false; // a completed pair of pixels whose second half is still in its tile buffer
-    int pair_x = 0;
-    for (int xg = xg0; EAST ? xg >= 0 : xg < Wp; xg += EAST ? -4 : 4) {
-        const int xlow = EAST ? xg - 3 : xg; // lowest column of the group
-        // this group's left census words and gray values; the next group's four window words (used at the shift below)
-        const u32x4 clv4 = *(const u32x4 *)(cl_r + xlow);
-        const u32 gray4 = *(const u32 *)(gray_r + xlow);
-        u32x4 wnew;
-        {
-            struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
-            const int nxt = EAST ? xlow - 4 - dbase - (DPL - 1) : xg + 4 - dbase + 1; // E: the four words below the window; W: above
-            wnew = ((const V4 *)(cr_r + nxt))->v;
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int x = EAST ? xg - p : xg + p;
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int off = EAST ? 3 - p : p; // window offset of this phase
-            const u32 clv = EAST ? (p == 0 ? clv4.w : p == 1 ? clv4.z : p == 2 ? clv4.y : clv4.x) : (p == 0 ? clv4.x : p == 1 ? clv4.y : p == 2 ? clv4.z : clv4.w);
-            const int I = (int)((gray4 >> (8 * (EAST ? 3 - p : p))) & 255u);
-            // ---- costs (pair i = disparities dbase + i and dbase + NP + i): w[j] = ww[off + j], d = dbase + DPL - 1 - j
-            u32 C[NP];
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                const u32 c0 = __popc(clv ^ ww[off + DPL - 1 - i]);
-                const u32 c1 = __popc(clv ^ ww[off + DPL - 1 - NP - i]);
-                C[i] = (c1 << 16) | c0;
-            }
-            if (x < D - 1) { // (uniform) some d > x: those cells cost InvalidDispCost
-                const int lim = x - dbase;
-#pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    const u32 lo = (i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
-                    const u32 hi = (NP + i <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
-                    C[i] = lo | (hi << 16);
-                }
-            }
-            const u32 P2pk = prevI < 0 ? 0u : s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)prevI, 0u)];
-            // ---- the update; the operands from the neighbouring chunks and the minimum were sent through the LDS crossbar
-            // at the end of the previous step and arrive under the cost computation above
-            const u32 mm = sgm_update_split_pn<NP>(L, C, P1pk, P2pk, minpk, prev, next);
-            prevI = I;
-            // ---- bytes in disparity order, pixel-major into an LDS tile [row][pixel of the pair][D].  A finished pair of
-            // pixels (2 * D bytes per row: whole 128-byte lines) leaves in two halves, the first right away, the second during
-            // the next step, from the other one of two tile buffers: half as many registers wait for the stores.  (One wave,
-            // in-order LDS queue: no barrier; the tile traffic is queued BEFORE the crossbar trips below, so that waiting for
-            // it does not wait for them.)
-            constexpr int NH = NST / 2 > 0 ? NST / 2 : 1; // pieces per half
-            u32x4 outv[NH];
-            const bool odd = (p & 1) == 1;
-            {
-                u32 tq[NP / 2], bw[NP / 2];
-#pragma unroll
-                for (int k = 0; k < NP / 2; k++) tq[k] = __builtin_amdgcn_perm(L[2 * k + 1], L[2 * k], 0x06020400u);
-#pragma unroll
-                for (int j = 0; j < NP / 4; j++) {
-                    bw[j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x05040100u);
-                    bw[NP / 4 + j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x07060302u);
-                }
-                u32 *tb = tr + (((p >> 1) & 1) ? TRH : 0); // buffer of this pair of pixels (two pairs per group of four steps)
-                u32x4 *wp = (u32x4 *)(tb + (g * 2 + (x & 1)) * (D / 4) + lg * (DPL / 4));
-#pragma unroll
-                for (int k = 0; k < NQ; k++) wp[k] = u32x4{bw[4 * k], bw[4 * k + 1], bw[4 * k + 2], bw[4 * k + 3]};
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                // odd step: first half of the pair just completed; even step: second half of the previous pair (other buffer)
-                const u32 *rb = odd ? tb : tr + (((p >> 1) & 1) ? 0 : TRH);
-#pragma unroll
-                for (int k = 0; k < NH; k++) outv[k] = *(const u32x4 *)(rb + ((odd ? 0 : NH) + k) * 256 + lane * 4);
-            }
-            // ---- next step's operands from the neighbouring chunks and this step's minimum over the pixel's four lanes:
-            // LDS crossbar trips that arrive under the next step's cost computation
-            {
-                const u32 pv = (u32)__builtin_amdgcn_ds_bpermute(bp_prev, (int)L[NP - 1]);
-                const u32 nx = (u32)__builtin_amdgcn_ds_bpermute(bp_next, (int)L[0]);
-                u32 m2 = min(mm, (u32)__builtin_amdgcn_ds_bpermute(bp_x16, (int)mm));
-                m2 = min(m2, (u32)__builtin_amdgcn_ds_bpermute(bp_x32, (int)m2));
-                minpk = pk_splat(m2);
-                prev = first ? NONE : pv;
-                next = last ? NONE : nx;
-            }
-            if (odd || have_pair) {
-                const int xs = odd ? (x & ~1) : pair_x; // even column of the pair the pieces belong to
-                const u32 colb = (u32)(y0 * Wp + xs) * (u32)D;
-#pragma unroll
-                for (int k = 0; k < NH; k++) {
-                    // the piece's place among 16 rows x 2 pixels x D bytes: its row, its offset in the row's pair
-                    const u32 b = (u32)((odd ? 0 : NH) + k) * 1024u + (u32)lane * 16u;
-                    __builtin_nontemporal_store(outv[k], (u32x4 *)(out_f + colb + (b / (2u * D)) * (u32)Wp * D + b % (2u * D)));
-                }
-            }
-            if (odd) {
-                have_pair = true;
-                pair_x = x & ~1;
-            }
-        }
-        // ---- shift the window by one group
-        if (EAST) {
-#pragma unroll
-            for (int j = DPL + 3; j >= 4; j--) ww[j] = ww[j - 4];
-            ww[0] = wnew.x; ww[1] = wnew.y; ww[2] = wnew.z; ww[3] = wnew.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < DPL; j++) ww[j] = ww[j + 4];
-            ww[DPL] = wnew.x; ww[DPL + 1] = wnew.y; ww[DPL + 2] = wnew.z; ww[DPL + 3] = wnew.w;
-        }
-    }
-    if (have_pair) { // the second half of the last pair (its buffer: the second of a group)
-        constexpr int NH = NST / 2 > 0 ? NST / 2 : 1;
-        const u32 colb = (u32)(y0 * Wp + pair_x) * (u32)D;
-#pragma unroll
-        for (int k = 0; k < NH; k++) {
-            const u32 b = (u32)(NH + k) * 1024u + (u32)lane * 16u;
-            const u32x4 v = *(const u32x4 *)(tr + TRH + (NH + k) * 256 + lane * 4);
-            __builtin_nontemporal_store(v, (u32x4 *)(out_f + colb + (b / (2u * D)) * (u32)Wp * D + b % (2u * D)));
-        }
-    }
-}
-
-template <int DPL>
-__global__ void __launch_bounds__(256, DPL <= 48 ? 3 : 2) sgm_horiz4_kernel(Horiz4Args a)
-{
-    constexpr int D = 4 * DPL, TRW = 2 * 32 * D / 4; // LDS words per wave: two tile buffers of 16 rows x 2 pixels x D bytes
-    __shared__ __attribute__((aligned(16))) u32 s_lut[256 + 4 * TRW];
-    s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
-    __syncthreads();
-    // blockIdx -> (frame, wave unit): with a batch that is a multiple of 8 frame f stays on XCD f % 8 (its census / gray
-    // rows in one L2), like sgm_paths_kernel
-    const int nrb = a.Hp / 16, upf = 2 * nrb, bpf = (upf + 3) / 4; // row blocks, wave units and blocks per frame
-    int f, within;
-    if (a.B % 8 == 0) {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-        f = (j / bpf) * 8 + xcd;
-        within = j % bpf;
-    } else {
-        f = blockIdx.x / bpf;
-        within = blockIdx.x % bpf;
-    }
-    const int unit = within * 4 + (int)(threadIdx.x >> 6);
-    if (unit >= upf) return;
-    const int dir = unit / nrb, rb = unit % nrb; // all W units of a frame, then its E units
-    const int lane = threadIdx.x & 63;
-    const int y0 = rb * 16, y = y0 + (lane & 15);
-    const size_t fpix = (size_t)f * a.Hp * a.Wp;
-    const u8 *gray_r = a.gray + fpix + (size_t)y * a.Wp;
-    const u32 *cl_r = a.cl + fpix + (size_t)y * a.Wp;
-    const u32 *cr_r = a.cr + fpix + (size_t)y * a.Wp;
-    u8 *out_f = a.out + (size_t)dir * a.vol_elems + fpix * D;
-    u32 *tr = s_lut + 256 + (threadIdx.x >> 6) * TRW;
-    if (dir == 0) horiz4_walk<DPL, false>(a, s_lut, tr, gray_r, cl_r, cr_r, out_f, y0, lane);
-    else horiz4_walk<DPL, true>(a, s_lut, tr, gray_r, cl_r, cr_r, out_f, y0, lane);
-}
-
-// The same walk with 8 lanes x DPL disparities per pixel and 8 rows per wave (lane = 8 * row + chunk, the lane layout of
-// sgm_paths_kernel<8, 24>): half the registers of the 16-row form, so that five waves share a SIMD and cover the walk's
-// long dependent chain (a step needs the minimum and the chunk-end operands of the step before), and the d +- 1 operands
-// and the minimum move by DPP inside the pixel's 8 adjacent lanes instead of through the LDS crossbar.
-template <int DPL, bool EAST>
-__device__ __forceinline__ void horiz8_walk(const Horiz4Args &a, const u32 *s_lut, u32 *tr, const u8 *gray_r, const u32 *cl_r,
-                                            const u32 *cr_r, u8 *out_f, int y0, int lane)
-{
-    constexpr int NP = DPL / 2, D = 8 * DPL, NE = DPL / 8, NST = D / 64; // NE = 8-byte pieces per lane, NST = stores per two pixels
-    const int r = lane >> 3, lg = lane & 7;
-    const int dbase = DPL * lg, Wp = a.Wp;
-    const bool first = lg == 0, last = lg == 7;
-    const u32 P1pk = pk_splat(a.p1 > 65535 ? 65535u : (u32)(a.p1 < 0 ? 0 : a.p1));
-    u32 L[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) L[i] = 0;
-    u32 minpk = 0;
-    u32 ww[DPL + 4];
-    const int xg0 = EAST ? Wp - 1 : 0;
-    {
-        const u32 *wp = cr_r + (xg0 - (EAST ? 3 : 0) - dbase - (DPL - 1));
-#pragma unroll
-        for (int q = 0; q < (DPL + 4) / 4; q++) {
-            struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
-            const u32x4 t = ((const V4 *)(wp + 4 * q))->v;
-            ww[4 * q] = t.x; ww[4 * q + 1] = t.y; ww[4 * q + 2] = t.z; ww[4 * q + 3] = t.w;
-        }
-    }
-    int prevI = -1;
-    for (int xg = xg0; EAST ? xg >= 0 : xg < Wp; xg += EAST ? -4 : 4) {
-        const int xlow = EAST ? xg - 3 : xg;
-        const u32x4 clv4 = *(const u32x4 *)(cl_r + xlow);
-        const u32 gray4 = *(const u32 *)(gray_r + xlow);
-        u32x4 wnew;
-        {
-            struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
-            const int nxt = EAST ? xlow - 4 - dbase - (DPL - 1) : xg + 4 - dbase + 1;
-            wnew = ((const V4 *)(cr_r + nxt))->v;
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int x = EAST ? xg - p : xg + p;
-            const int off = EAST ? 3 - p : p;
-            const u32 clv = EAST ? (p == 0 ? clv4.w : p == 1 ? clv4.z : p == 2 ? clv4.y : clv4.x) : (p == 0 ? clv4.x : p == 1 ? clv4.y : p == 2 ? clv4.z : clv4.w);
-            const int I = (int)((gray4 >> (8 * (EAST ? 3 - p : p))) & 255u);
-            u32 C[NP];
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                const u32 c0 = __popc(clv ^ ww[off + DPL - 1 - i]);
-                const u32 c1 = __popc(clv ^ ww[off + DPL - 1 - NP - i]);
-                C[i] = (c1 << 16) | c0;
-            }
-            if (x < D - 1) {
-                const int lim = x - dbase;
-#pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    const u32 lo = (i <= lim) ? (C[i] & 0xFFFFu) : INVALID_DISP_COST;
-                    const u32 hi = (NP + i <= lim) ? (C[i] >> 16) : INVALID_DISP_COST;
-                    C[i] = lo | (hi << 16);
-                }
-            }
-            const u32 P2pk = prevI < 0 ? 0u : s_lut[__builtin_amdgcn_sad_u8((u32)I, (u32)prevI, 0u)];
-            sgm_update_split<NP, 8>(L, C, P1pk, P2pk, minpk, first, last);
-            prevI = I;
-            {
-                u32 tq[NP / 2], bw[NP / 2];
-#pragma unroll
-                for (int k = 0; k < NP / 2; k++) tq[k] = __builtin_amdgcn_perm(L[2 * k + 1], L[2 * k], 0x06020400u);
-#pragma unroll
-                for (int j = 0; j < NP / 4; j++) {
-                    bw[j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x05040100u);
-                    bw[NP / 4 + j] = __builtin_amdgcn_perm(tq[2 * j + 1], tq[2 * j], 0x07060302u);
-                }
-                u32x2 *wp = (u32x2 *)(tr + (r * 2 + (x & 1)) * (D / 4) + lg * (DPL / 4)); // tile [row][pixel of the pair][D]
-#pragma unroll
-                for (int k = 0; k < NE; k++) wp[k] = u32x2{bw[2 * k], bw[2 * k + 1]};
-            }
-            if ((p & 1) == 1) { // two pixels of every row are in the tile: whole lines (one wave, in-order LDS queue)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const u32 colb = (u32)(y0 * Wp + (x & ~1)) * (u32)D;
-#pragma unroll
-                for (int k = 0; k < NST; k++) {
-                    const u32 b = (u32)k * 1024u + (u32)lane * 16u; // among 8 rows x 2 pixels x D bytes
-                    const u32x4 v = *(const u32x4 *)(tr + k * 256 + lane * 4);
-                    __builtin_nontemporal_store(v, (u32x4 *)(out_f + colb + (b / (2u * D)) * (u32)Wp * D + b % (2u * D)));
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-        if (EAST) {
-#pragma unroll
-            for (int j = DPL + 3; j >= 4; j--) ww[j] = ww[j - 4];
-            ww[0] = wnew.x; ww[1] = wnew.y; ww[2] = wnew.z; ww[3] = wnew.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < DPL; j++) ww[j] = ww[j + 4];
-            ww[DPL] = wnew.x; ww[DPL + 1] = wnew.y; ww[DPL + 2] = wnew.z; ww[DPL + 3] = wnew.w;
-        }
-    }
-}
-
-template <int DPL>
-__global__ void __launch_bounds__(256, DPL <= 24 ? 5 : 4) sgm_horiz8_kernel(Horiz4Args a)
-{
-    constexpr int D = 8 * DPL, TRW = 16 * D / 4; // LDS words per wave: 8 rows x 2 pixels x D bytes
-    __shared__ __attribute__((aligned(16))) u32 s_lut[256 + 4 * TRW];
-    s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
-    __syncthreads();
-    const int nrb = a.Hp / 8, upf = 2 * nrb, bpf = (upf + 3) / 4;
-    int f, within;
-    if (a.B % 8 == 0) {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-        f = (j / bpf) * 8 + xcd;
-        within = j % bpf;
-    } else {
-        f = blockIdx.x / bpf;
-        within = blockIdx.x % bpf;
-    }
-    const int unit = within * 4 + (int)(threadIdx.x >> 6);
-    if (unit >= upf) return;
-    const int dir = unit / nrb, rb = unit % nrb;
-    const int lane = threadIdx.x & 63;
-    const int y0 = rb * 8, y = y0 + (lane >> 3);
-    const size_t fpix = (size_t)f * a.Hp * a.Wp;
-    const u8 *gray_r = a.gray + fpix + (size_t)y * a.Wp;
-    const u32 *cl_r = a.cl + fpix + (size_t)y * a.Wp;
-    const u32 *cr_r = a.cr + fpix + (size_t)y * a.Wp;
-    u8 *out_f = a.out + (size_t)dir * a.vol_elems + fpix * D;
-    u32 *tr = s_lut + 256 + (threadIdx.x >> 6) * TRW;
-    if (dir == 0) horiz8_walk<DPL, false>(a, s_lut, tr, gray_r, cl_r, cr_r, out_f, y0, lane);
-    else horiz8_walk<DPL, true>(a, s_lut, tr, gray_r, cl_r, cr_r, out_f, y0, lane);
-}
-
-int rsgm_launch_horiz8(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut,
-                       int p1, void *paths)
-{
-    Horiz4Args a;
-    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.out = (u8 *)paths;
-    a.B = B; a.Hp = Hp; a.Wp = Wp;
-    a.p1 = p1 > 231 ? 231 : p1;
-    a.vol_elems = (size_t)B * Hp * Wp * D;
-    const int bpf = (2 * (Hp / 8) + 3) / 4;
-    const dim3 grid((unsigned)(bpf * B));
-    if (D == 64) sgm_horiz8_kernel<8><<<grid, 256, 0, ctx->stream>>>(a);
-    else if (D == 128) sgm_horiz8_kernel<16><<<grid, 256, 0, ctx->stream>>>(a);
-    else if (D == 192) sgm_horiz8_kernel<24><<<grid, 256, 0, ctx->stream>>>(a);
-    else sgm_horiz8_kernel<32><<<grid, 256, 0, ctx->stream>>>(a);
-    VPPX_CHECK_LAUNCH();
-    return 0;
-}
-
-bool rsgm_horiz4_supported(int Hp, int Wp, int D)
-{
-    return (D == 64 || D == 128 || D == 192 || D == 256) && Hp % 16 == 0 && Wp % 4 == 0 && (size_t)Hp * Wp * D < ((size_t)1 << 32);
-}
-
-int rsgm_launch_horiz4(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut,
-                       int p1, void *paths)
-{
-    Horiz4Args a;
-    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.out = (u8 *)paths;
-    a.B = B; a.Hp = Hp; a.Wp = Wp;
-    a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (rsgm_launch_paths)
-    a.vol_elems = (size_t)B * Hp * Wp * D;
-    const int bpf = (2 * (Hp / 16) + 3) / 4;
-    const dim3 grid((unsigned)(bpf * B));
-    if (D == 64) sgm_horiz4_kernel<16><<<grid, 256, 0, ctx->stream>>>(a);
-    else if (D == 128) sgm_horiz4_kernel<32><<<grid, 256, 0, ctx->stream>>>(a);
-    else if (D == 192) sgm_horiz4_kernel<48><<<grid, 256, 0, ctx->stream>>>(a);
-    else sgm_horiz4_kernel<64><<<grid, 256, 0, ctx->stream>>>(a);
-    VPPX_CHECK_LAUNCH();
-    return 0;
-}
-
 // The lock-step hand-off goes through ONE L2: all blocks of a (frame, pass) group must run on the same XCD, which the
 // kernel gets from "consecutive block ids go round-robin over the XCDs" (group blocks are 8 ids apart).  Checked once
 // per context on the device it runs on: 256 blocks report the XCD they run on (also true, trivially, when the device is

@@ -174,12 +174,6 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
         // bounds of one neighbour wait in the fused aggregation kernel: milliseconds of wall clock (the bound that counts)
         // and, for tests that must see the give-up path, a number of polls (1 = give up at the first record not there yet)
-        e = getenv("VPPX_WE4");
-        if (e) ctx->we4 = atoi(e);
-        e = getenv("VPPX_PIPE_EARLY");
-        if (e) ctx->pipe_early = atoi(e);
-        e = getenv("VPPX_WE_OVERLAP");
-        if (e) ctx->we_overlap = atoi(e);
         e = getenv("VPPX_V3_TIMEOUT_MS");
         if (e && atoi(e) > 0) ctx->v3.timeout_ms = atoi(e);
         e = getenv("VPPX_V3_PPW");
@@ -217,7 +211,6 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (ctx->ev_front_done) (void)hipEventDestroy(ctx->ev_front_done);
     if (ctx->ev_inputs_auto) (void)hipEventDestroy(ctx->ev_inputs_auto);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->stream_we) (void)hipStreamDestroy(ctx->stream_we);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
@@ -516,12 +509,11 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         if ((rc = ws_get(ctx, WS_SV, ncell * 2, &sv))) return rc;
         if ((rc = ws_get(ctx, WS_VSTATE, vert3 ? rsgm_vert3_xbuf_bytes(g.B, g.Wp, g.D) : rsgm_vert_state_bytes(g.B, g.Wp, g.D), &gst))) return rc;
         if ((rc = ws_get(ctx, WS_VMIN, vert3 ? 8 : rsgm_vert_min_elems(g.B, g.Wp), &gmin))) return rc;
-        // W and E: 16 rows per wave (sgm_horiz4_kernel) next to the fused vertical kernels; VPPX_WE4=0 keeps the line kernel
+        // W and E stay on the line-parallel kernel.  (Round 3 built the fused kernels' lane layouts turned by 90 degrees for
+        // them -- 16 or 8 rows per wave, the right-image census window kept in registers and shifted by one word per step:
+        // 19 instead of 26 instructions per pixel, bit-exact -- and measured 1.88-2.10 ms (16 rows, 168 VGPRs: 2-3 waves per
+        // SIMD cannot cover the walk's dependent chain) and 2.6 ms (8 rows: 96 VGPRs only with spills) against 1.94-2.00.)
         auto launch_we = [&]() -> int {
-            if (vert3 && ctx->we4 == 8 && rsgm_horiz4_supported(g.Hp, g.Wp, g.D))
-                return rsgm_launch_horiz8(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, paths);
-            if (vert3 && ctx->we4 == 4 && rsgm_horiz4_supported(g.Hp, g.Wp, g.D))
-                return rsgm_launch_horiz4(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, paths);
             return rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11);
         };
         auto launch_vert = [&](hipStream_t st) -> int {
@@ -551,31 +543,9 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             }
             return r;
         };
-        if (which == 0 && vert3 && ctx->we_overlap > 0 && !ctx->capturing) {
-            // experiment (VPPX_WE_OVERLAP): W/E on a side stream (2: high priority) so that the fused kernel's first groups
-            // can start in the W/E launch's second, sparsely filled round
-            if (!ctx->stream_we) {
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                VPPX_HIP(hipStreamCreateWithPriority(&ctx->stream_we, hipStreamNonBlocking, ctx->we_overlap >= 2 ? hi : lo));
-            }
-            VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-            VPPX_HIP(hipStreamWaitEvent(ctx->stream_we, ctx->ev_fork, 0));
-            hipStream_t main_stream = ctx->stream;
-            ctx->stream = ctx->stream_we;
-            rc = launch_we();
-            ctx->stream = main_stream;
-            if (rc) return rc;
-            VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream_we));
-            if ((rc = launch_vert(ctx->stream))) return rc;
-            VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        } else if (which == 0 && vert3) {
+        if (which == 0 && vert3) {
             // one after the other: both launches fill the chip, two streams only interleave them (measured: no gain)
             if ((rc = launch_we())) return rc;
-            if (ctx->pipe_call && ctx->pipe_early == 2) { // experiment: the next front stage starts next to the fused vertical kernel
-                VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
-                ctx->have_agg_done = true;
-            }
             if ((rc = launch_vert(ctx->stream))) return rc;
         } else if (which == 0) {
             VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -677,16 +647,6 @@ static int front_end(vppx_ctx *ctx)
     for (int i = 0; i < ctx->n_pipe_copy; i++)
         VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_pipe_copy = 0;
-    if (ctx->pipe_call && ctx->pipe_early == 1) {
-        // From here on nothing of this call reads what a front stage writes, except the gray / census images the
-        // aggregation takes -- and those alternate between two sets by call parity.  The NEXT call's front stage may
-        // therefore start now, next to this call's aggregation (it fills the sparsely occupied second round of the W/E
-        // launch and the registers the fused kernel leaves free) instead of next to its sum / WTA kernel, which leaves no LDS.
-        // Set p is rewritten by front stage k+2, which waits for THIS event of call k+1, recorded on the in-order launch
-        // stream behind call k's aggregation.
-        VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
-        ctx->have_agg_done = true;
-    }
     return 0;
 }
 struct FrontGuard { // error paths: never leave the context on the front stream
@@ -710,14 +670,11 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const size_t ncell = npp * g.D;
     u8 *gl, *glv, *grv;
     u32 *cl, *cr_raw;
-    // (pipelined calls alternate between two sets of the images the aggregation reads: see front_end)
-    const bool alt = ctx->pipe_call && ctx->pipe_early && (ctx->pipe_parity & 1);
-    if (ctx->pipe_call) ctx->pipe_parity ^= 1;
-    if ((rc = ws_get(ctx, alt ? WS_GRAY_L2 : WS_GRAY_L, npp, &gl))) return rc;
+    if ((rc = ws_get(ctx, WS_GRAY_L, npp, &gl))) return rc;
     if ((rc = ws_get(ctx, WS_GRAY_LV, npp, &glv))) return rc;
     if ((rc = ws_get(ctx, WS_GRAY_RV, npp, &grv))) return rc;
-    if ((rc = ws_get(ctx, alt ? WS_CENSUS_L2 : WS_CENSUS_L, npp, &cl))) return rc;
-    if ((rc = ws_get(ctx, alt ? WS_CENSUS_R2 : WS_CENSUS_R, npp + 512 + 64, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads), 64 behind (sgm_horiz4_kernel loads its window a group of four columns ahead)
+    if ((rc = ws_get(ctx, WS_CENSUS_L, npp, &cl))) return rc;
+    if ((rc = ws_get(ctx, WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
     u32 *cr = cr_raw + 512;
     ctx->last_gl = gl; ctx->last_cl = cl; ctx->last_cr = cr;
     {
@@ -746,7 +703,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const void *vols[8];
     int nvol = 0, elem_bytes = 1;
     if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0, hints, validhints))) return rc;
-    if (ctx->pipe_call && !ctx->pipe_early) { // the next pipelined call's front stage may start now
+    if (ctx->pipe_call) { // the next pipelined call's front stage may start now
         VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
         ctx->have_agg_done = true;
     }

@@ -62,9 +62,6 @@ enum WsSlot {
     WS_GRAY_RV,
     WS_CENSUS_L,
     WS_CENSUS_R,
-    WS_GRAY_L2,      // second set of the images the aggregation reads (pipelined calls alternate: vppx_set_pipeline)
-    WS_CENSUS_L2,
-    WS_CENSUS_R2,
     WS_PATHS,        // 8 per-path L volumes
     WS_S,            // aggregated volume (u16)
     WS_SV,           // per-pass sums of the vertical/diagonal paths (band-marching kernel)
@@ -109,9 +106,6 @@ struct vppx_ctx {
     bool own_stream = false;
     bool legacy_stream = false;    // launches go to the legacy default (null) stream: vppx_set_stream_legacy
     hipStream_t stream2 = nullptr; // side stream: horizontal paths overlap the vertical band launches
-    hipStream_t stream_we = nullptr; // W/E launch of the fused layout when it overlaps the vertical kernel (we_overlap)
-    int we_overlap = 0;
-    int we4 = 8;                     // W/E of the fused layout: 8 = sgm_horiz8_kernel, 4 = sgm_horiz4_kernel, 0 = the line-parallel kernel (VPPX_WE4)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // sub-contexts: the fused batched call splits its frames over `nsub` child contexts (own stream
     // and arena) so that latency-bound stages of one part overlap bandwidth-bound stages of another
@@ -128,8 +122,6 @@ struct vppx_ctx {
     bool front_active = false;     // ctx->stream currently is stream_front
     bool pipe_call = false;        // the running vpp_rsgm call is pipelined (record ev_agg_done after its aggregation)
     bool have_agg_done = false;
-    int pipe_early = 0;           // VPPX_PIPE_EARLY=1 (experiment, measured slower): the next front stage starts next to this call's aggregation instead of next to its sum / WTA
-    int pipe_parity = 0;           // which set of gray / census images the next pipelined call writes
     const u8 *last_gl = nullptr;   // the images the last call aggregated from (timing helpers)
     const u32 *last_cl = nullptr, *last_cr = nullptr;
     hipStream_t stream_front = nullptr, main_saved = nullptr;
@@ -262,11 +254,6 @@ bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err);
-bool rsgm_horiz4_supported(int Hp, int Wp, int D);
-int rsgm_launch_horiz4(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut,
-                       int p1, void *paths);
-int rsgm_launch_horiz8(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut,
-                       int p1, void *paths);
 bool rsgm_vert_supported(int D, int maxp2);
 size_t rsgm_vert_state_bytes(int B, int Wp, int D);
 size_t rsgm_vert_min_elems(int B, int Wp);
