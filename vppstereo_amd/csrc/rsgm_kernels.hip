@@ -2242,7 +2242,9 @@ struct VolPtrs {
 // GL = lanes per pixel (16; 8 for the byte volumes of D = 128 / 192, round 3: per-pixel overhead -- cross-lane merges, ring
 // addressing, cursors -- is paid per lane, and the kernel is bound by instruction issue).  FAST variants finalise a pixel
 // once, not GL times (top2_reduce / top2_final): a lane keeps the keys of ONE pixel per GL rounds.
-template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false, int GL = 16>
+// FULLW: the padded width is a multiple of the round (no partial tile: the per-pixel "inside the row" tests and the divergent
+// regions they open disappear).
+template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false, int GL = 16, bool FULLW = false>
 __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float *__restrict__ disp_l,
                                                           float *__restrict__ disp_r, int Hp, int Wp, u32 factor_uniq,
                                                           int do_subpixel, int rows_per_block)
@@ -2289,10 +2291,13 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
     // four volumes (fused vertical layout) leave room for a third operand set: three rounds of HBM latency covered
     constexpr int PF = (NV == 4 && sizeof(IT) == 1) ? 3 : 2;
     u32 wa[NV][NWD], wb[NV][NWD], wc[PF == 3 ? NV : 1][PF == 3 ? NWD : 1];
+    // (always issued, also past the end of the block's stream, where it re-reads the last row: a fetch under a condition makes
+    // the compiler shuffle whole operand sets between registers at the join)
     auto fetch = [&](u32 (&w)[NV][NWD]) {
         int x = T * f_k + g;
-        x = x < Wp ? x : Wp - 1;
-        const size_t rowoff = (framepix + (size_t)f_row * Wp) * D; // uniform: scalar base + 32-bit lane offset
+        if (!FULLW) x = x < Wp ? x : Wp - 1;
+        const int frow = f_row < r0 + nrows ? f_row : r0 + nrows - 1;
+        const size_t rowoff = (framepix + (size_t)frow * Wp) * D; // uniform: scalar base + 32-bit lane offset
         // FAST: cells with d > x + 1 have no reader (left WTA: d <= x, its sub-pixel step d <= x + 1; the right view reads
         // S[x][d] for the right pixel x - d >= 0): such a lane re-reads the pixel's first chunk (same cache lines as its
         // neighbours' loads: no extra HBM sectors, no branch) -- 9 % fewer bytes fetched at 960 x 192
@@ -2347,8 +2352,8 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
                     }
                 }
             }
-            if (j + PF < total) fetch(w); // this register set is free again
-            if (x < Wp) { // uniform per 16-lane group
+            fetch(w); // this register set is free again
+            if (FULLW || x < Wp) { // uniform per 16-lane group
                 u16 *t = ring + l_slot * TS + g;
 #pragma unroll
                 for (int i = 0; i < NP; i++) {
@@ -2378,7 +2383,7 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
         __syncthreads();
         if (j >= NR - 1) {
             const int xr = T * r_k + g;
-            if (xr < Wp) {
+            if (FULLW || xr < Wp) {
                 const int n = (Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1;
                 u32 sr[NP];
                 if constexpr (FAST) {
@@ -2442,9 +2447,9 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
         if (!SPARE) __syncthreads();
     };
     fetch(wa);
-    if (total > 1) fetch(wb);
+    fetch(wb);
     if constexpr (PF == 3) {
-        if (total > 2) fetch(wc);
+        fetch(wc);
         for (int j = 0; j < total + NR - 1; j += 3) {
             round(j, wa);
             if (j + 1 < total + NR - 1) round(j + 1, wb);
@@ -2459,9 +2464,12 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
     if constexpr (FAST) flush();
 }
 
-template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false, int GL = 16>
+template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false, int GL = 16, bool FULLW = false>
 static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
 {
+    if constexpr (FAST && !FULLW) { // whole tiles only: the variant without per-pixel row-end tests
+        if (Wp % T == 0) return launch_lr_t2<DPL, IT, NV, T, SPARE, SW4, FAST, GL, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+    }
     constexpr int D = GL * DPL;
     constexpr int NR = (T + D - 2) / T + 1;
     constexpr int NT = NR + (SPARE ? 1 : 0);
@@ -2469,7 +2477,7 @@ static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp,
     static bool attr_set[VPPX_MAX_DEVICES] = {}; // function attributes are per device
     const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
     if (!attr_set[dv]) {
-        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST, GL>,
+        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST, GL, FULLW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dv] = true;
     }
@@ -2499,7 +2507,7 @@ static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp,
     }
     const int rpb = (Hp + chunks - 1) / chunks;
     chunks = (Hp + rpb - 1) / rpb;
-    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST, GL><<<dim3(chunks, B), GL * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
+    sum_wta_lr_kernel<DPL, IT, NV, T, SPARE, SW4, FAST, GL, FULLW><<<dim3(chunks, B), GL * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
     VPPX_CHECK_LAUNCH();
     return 0;
 }
