@@ -272,13 +272,15 @@ int vppx_raft_corr_modulate_dev(vppx_ctx *ctx, float *corr, const float *hints, 
  * text header) -> float32 [H,W(,3)] flipped upside-down, byte-swapped if big-endian (readPFM :34-64).
  * Inflating the PNG stays with the host's image library. */
 int vppx_kitti_disp_decode_dev(vppx_ctx *ctx, const uint16_t *png_u16, int64_t n, float *disp, uint8_t *valid);
-/* Whole PNG FILES decoded on the device (chunk walk, zlib/DEFLATE inflate, scanline unfiltering), one workgroup per
- * file of a batch: `blob` (device) holds n_files files back to back, `offsets` (HOST, n_files + 1 entries) their
- * byte ranges.  Non-interlaced gray 8/16 bit (C = 1) or RGB 8 bit (C = 3), all files H x W.  disp/valid (C = 1):
+/* Whole PNG FILES decoded on the device (chunk walk, zlib/DEFLATE inflate, scanline unfiltering), one wave per
+ * file of a batch: `blob` (device) holds n_files files back to back -- no alignment or padding is required of it --,
+ * `offsets` (HOST, n_files + 1 entries) their byte ranges.  Non-interlaced gray 8/16 bit (C = 1) or RGB 8 bit (C = 3), all files H x W.  disp/valid (C = 1):
  * disp = sample * scale as float32 (scale 1/256 = readDispKITTI frame_utils.py:66-69, 1 = readDispMidd :71-74),
  * valid = disp > 0; out_u8 [n,H,W,C]: the 8-bit samples.  status (device int32 [n_files], may be NULL): 0 = ok,
  * 1 signature, 2 IHDR, 3 unsupported format, 4 size mismatch, 5 bad stream, 6 bad Huffman code, 7 bad filter,
- * 8 truncated; a failed file leaves its outputs untouched. */
+ * 8 truncated, 9 Adler-32 of the inflated stream does not match the one in the file (chunk CRCs are not verified); a file that
+ * fails before its first scanline leaves its outputs untouched, one that fails later has written the scanlines decoded so far.
+ * Scanlines up to 16 KB (1 + W * bytes per pixel). */
 int vppx_png_decode_dev(vppx_ctx *ctx, int n_files, const uint8_t *blob, const int64_t *offsets, int H, int W, int C,
                         float scale, float *disp, uint8_t *valid, uint8_t *out_u8, int32_t *status);
 int vppx_pfm_decode_dev(vppx_ctx *ctx, const uint8_t *raw, int H, int W, int channels, int little_endian, float *out);

@@ -171,3 +171,33 @@ def test_rejected_files(eng):
     corrupt[k] ^= 0xFF                                        # garbage inside the deflate stream
     with pytest.raises(ValueError):
         eng.png_decode([bytes(corrupt)], 20, 33)
+
+
+def test_adler32_of_the_inflated_stream_is_verified(eng):
+    """zlib ends with the Adler-32 of the inflated bytes (RFC 1950); cv2.imread / PIL reject a file whose checksum is wrong,
+    and so does the device decoder (status 9).  The checksum is the last four bytes of the last IDAT payload."""
+    rng = np.random.default_rng(6)
+    d = _kitti_like(rng, 40, 90)
+    good = _raw_png(d, extra=False)
+    disp, _ = eng.png_decode([good], 40, 90)
+    assert np.array_equal(disp[0].cpu().numpy(), (d / 256.0).astype(np.float32))
+    bad = bytearray(good)
+    k = good.rindex(b"IEND") - 4 - 4 - 1     # last byte of the last IDAT payload (before its CRC and the IEND length field)
+    bad[k] ^= 0x01
+    with pytest.raises(ValueError, match="status 9"):
+        eng.png_decode([bytes(bad)], 40, 90)
+
+
+def test_batch_of_kitti_sized_files_unaligned_blob(eng):
+    """32 files of different sizes back to back: no alignment or padding is required of the blob."""
+    rng = np.random.default_rng(7)
+    files, want = [], []
+    for i in range(32):
+        d = _kitti_like(rng, 375, 1242, p=0.05 + 0.01 * i)
+        files.append(_pil_png(d, compress_level=6 if i % 2 else 3))
+        want.append(d)
+    assert len({len(f) % 16 for f in files}) > 1
+    disp, valid = eng.png_decode(files, 375, 1242)
+    disp = disp.cpu().numpy()
+    for i, d in enumerate(want):
+        assert np.array_equal(disp[i], (d / 256.0).astype(np.float32)), i

@@ -14,8 +14,8 @@
 struct PngJobs {
     const u8 *blob;        // the files of the batch, back to back
     const long long *offs; // [n + 1] byte offsets into blob (device)
-    u8 *raw;               // [n][raw_stride] inflated scanlines (scratch)
-    size_t raw_stride;
+    u8 *zcat;              // scratch: the concatenated IDAT payloads of file i start at zcat + zoffs[i] (16-byte aligned)
+    const long long *zoffs; // [n] (device)
     float *disp;           // [n][H][W] or null
     u8 *valid;             // [n][H][W] or null
     u8 *out_u8;            // [n][H][W][C] or null (8-bit images)
@@ -25,95 +25,167 @@ struct PngJobs {
 };
 
 enum { PNG_OK = 0, PNG_E_SIG = 1, PNG_E_IHDR = 2, PNG_E_UNSUPPORTED = 3, PNG_E_SIZE = 4, PNG_E_STREAM = 5, PNG_E_HUFF = 6,
-       PNG_E_FILTER = 7, PNG_E_TRUNC = 8 };
+       PNG_E_FILTER = 7, PNG_E_TRUNC = 8, PNG_E_ADLER = 9 };
 
-// ---- byte source: walks the IDAT chunks of one file ------------------------------------------------------
-struct IdatReader {
-    const u8 *f;     // file
-    long long n;     // file size
-    long long pos;   // next byte of the current IDAT payload
-    long long end;   // end of the current IDAT payload
-    int err;
-    u32 bitbuf;
-    int bitcnt;
-    u32 cache;                 // the aligned 4-byte word that holds the last byte read (one global load per 4 bytes)
-    unsigned long long cache_a;
-    __device__ u32 be32(long long p) const { return ((u32)f[p] << 24) | ((u32)f[p + 1] << 16) | ((u32)f[p + 2] << 8) | (u32)f[p + 3]; }
-    __device__ bool next_chunk()
-    { // position on the next IDAT chunk (pos = end = end of a payload, followed by its 4-byte CRC)
-        long long p = end + 4;
-        while (p + 12 <= n) {
-            const u32 len = be32(p);
-            const u32 type = be32(p + 4);
-            if (type == 0x49444154u) { // "IDAT"
-                pos = p + 8;
-                end = pos + len;
-                if (end + 4 > n) { err = PNG_E_TRUNC; return false; }
-                if (len == 0) { p = end + 4; continue; }
-                return true;
-            }
-            if (type == 0x49454E44u) break; // "IEND"
-            p += 12 + (long long)len;
+// ---------------------------------------------------------------------------------------
+// Round 3: the decoder is ONE WAVE PER FILE running uniform code (every lane follows the same control flow on the same
+// values), with everything the serial part touches staged in LDS:
+//   * the IDAT payloads are first concatenated into a scratch stream by all lanes (coalesced copies; the chunk walk is a
+//     few dozen dependent loads); the inflate then reads that stream through an 8 KB LDS window refilled 4 KB at a time;
+//   * the LZ77 window is a 64 KB ring in LDS: literals are one LDS byte store, matches are copied by all lanes at once (a
+//     match that overlaps itself repeats with period `dist`, so out[n + i] = out[n - dist + i % dist] has no dependence
+//     inside the copy);
+//   * Huffman symbols come from 10-bit (literal/length) and 9-bit (distance) primary tables built by all lanes per block,
+//     longer codes from the canonical bit-serial walk; the bit buffer is refilled 32 bits at a time;
+//   * a scanline is unfiltered and converted the moment the inflate has produced it, from the ring into a row buffer
+//     (the ring keeps the FILTERED stream, which later matches refer to): None / Up in parallel, Sub as a wave scan,
+//     Average / Paeth serially; the inflated stream never goes to HBM;
+//   * the zlib Adler-32 is accumulated per scanline (parallel sums) and checked.
+// The first version read every compressed byte and every back-reference from global memory with ONE lane (a dependent
+// ~1 us load per 4 bytes): 0.44 s for one 375 x 1242 16-bit map; this one: see DESIGN.md section 8.
+// ---------------------------------------------------------------------------------------
+#define PNG_IN_SZ 8192
+#define PNG_RING 65536
+#define PNG_ROWMAX 16384
+#define PNG_LBITS 10
+#define PNG_DBITS 9
+
+struct PngLds {
+    u8 *in;      // [PNG_IN_SZ] window of the compressed stream
+    u8 *ring;    // [PNG_RING] inflated (filtered) stream
+    u8 *row[2];  // [PNG_ROWMAX] unfiltered previous / current scanline
+    u16 *tab_l;  // [1 << PNG_LBITS] sym << 4 | len, 0xFFFF = longer code
+    u16 *tab_d;  // [1 << PNG_DBITS]
+    u16 *cnt_l, *sym_l, *cnt_d, *sym_d; // canonical tables (huff_build)
+    u8 *lens;    // [320]
+};
+
+// The decoder's state is the same in every lane.  Telling the compiler so -- every value that comes out of LDS passes
+// through v_readfirstlane -- keeps that state in SGPRs: scalar ALU, scalar branches, no exec masking, no spills.
+__device__ __forceinline__ u32 sld32(const u32 *p) { return (u32)__builtin_amdgcn_readfirstlane((int)*p); }
+__device__ __forceinline__ u32 sld16(const u16 *p) { return (u32)__builtin_amdgcn_readfirstlane((int)*p); }
+__device__ __forceinline__ u32 sld8(const u8 *p) { return (u32)__builtin_amdgcn_readfirstlane((int)*p); }
+
+struct BitReader { // uniform: every lane holds the same state
+    const u8 *z;       // concatenated stream (global, 16-byte aligned)
+    u32 zlen;          // its length in bytes
+    u8 *in;            // LDS window
+    unsigned long long bb;
+    int bc;            // bits in bb
+    u32 word;          // next 32-bit word of the stream to enter bb
+    __device__ __forceinline__ void fill_half(u32 first_word, int lane)
+    { // words [first_word, first_word + 1024) -> window (zeros past the end of the stream); all lanes
+        u32 *dst = (u32 *)in;
+        for (int k = lane; k < 1024; k += 64) {
+            const u32 w = first_word + (u32)k, b = w * 4u;
+            u32 v = 0;
+            if (b + 4u <= zlen) v = *(const u32 *)(z + b);
+            else if (b < zlen) { for (u32 q = b; q < zlen; q++) v |= (u32)z[q] << (8u * (q - b)); }
+            dst[w & 2047u] = v;
         }
-        err = PNG_E_TRUNC;
-        return false;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __device__ u32 byte()
+    __device__ void init(int lane)
     {
-        if (pos >= end && !next_chunk()) return 0;
-        const unsigned long long a = (unsigned long long)(f + pos);
-        pos++;
-        if ((a & ~3ull) != cache_a) { // (the blob is padded: an aligned word never leaves the allocation)
-            cache_a = a & ~3ull;
-            cache = *(const u32 *)cache_a;
-        }
-        return (cache >> ((a & 3ull) * 8)) & 255u;
+        bb = 0; bc = 0; word = 0;
+        fill_half(0, lane);
+        fill_half(1024, lane);
     }
-    __device__ u32 bits(int k)
-    { // k <= 16, LSB first (RFC 1951 3.1.1)
-        while (bitcnt < k) {
-            bitbuf |= byte() << bitcnt;
-            bitcnt += 8;
+    __device__ __forceinline__ void ensure(int lane)
+    { // afterwards bc > 32
+        if (bc <= 32) {
+            const u32 v = sld32((const u32 *)in + (word & 2047u));
+            bb |= (unsigned long long)v << bc;
+            bc += 32;
+            word++;
+            if ((word & 1023u) == 0) fill_half(word + 1024u, lane); // the half just consumed takes the data after the other half
         }
-        const u32 v = bitbuf & ((1u << k) - 1u);
-        bitbuf >>= k;
-        bitcnt -= k;
+    }
+    __device__ __forceinline__ u32 peek(int k) const { return (u32)bb & ((1u << k) - 1u); } // k <= 16
+    __device__ __forceinline__ void drop(int k) { bb >>= k; bc -= k; }
+    __device__ __forceinline__ u32 bits(int k, int lane)
+    {
+        ensure(lane);
+        const u32 v = peek(k);
+        drop(k);
         return v;
     }
+    __device__ bool overrun() const { return (unsigned long long)word * 32ull - (unsigned long long)bc > (unsigned long long)zlen * 8ull; }
 };
 
 // canonical Huffman code given by the number of codes of each length and the symbols in code order (RFC 1951 3.2.2)
-struct Huff {
-    u16 *count; // [16]
-    u16 *sym;   // [n symbols]
-};
-
-__device__ int huff_build(const Huff &h, const u8 *len, int n)
+__device__ __noinline__ int png_huff_build(u16 *count, u16 *sym, const u8 *len, int n)
 {
-    for (int i = 0; i < 16; i++) h.count[i] = 0;
-    for (int i = 0; i < n; i++) h.count[len[i]]++;
-    if (h.count[0] == n) return 0; // no codes (allowed for the distance alphabet)
+    for (int i = 0; i < 16; i++) count[i] = 0;
+    for (int i = 0; i < n; i++) count[len[i]]++;
+    if (count[0] == n) return 0; // no codes (allowed for the distance alphabet)
     int left = 1;
     for (int l = 1; l < 16; l++) {
         left <<= 1;
-        left -= h.count[l];
+        left -= count[l];
         if (left < 0) return -1; // over-subscribed
     }
     u16 offs[16];
     offs[1] = 0;
-    for (int l = 1; l < 15; l++) offs[l + 1] = offs[l] + h.count[l];
+    for (int l = 1; l < 15; l++) offs[l + 1] = offs[l] + count[l];
     for (int i = 0; i < n; i++)
-        if (len[i]) h.sym[offs[len[i]]++] = (u16)i;
+        if (len[i]) sym[offs[len[i]]++] = (u16)i;
     return left; // > 0: incomplete code
 }
 
-__device__ int huff_decode(IdatReader &r, const Huff &h)
+// primary decode table of TB bits from the canonical tables (all lanes): entry = sym << 4 | len for codes of at most TB bits
+// (replicated over the unused high bits; the stream is LSB first, so the table is indexed by the bit-reversed code), 0xFFFF
+// where a longer code starts
+template <int TB>
+__device__ __noinline__ void png_table_build(u16 *tab, const u16 *count, const u16 *sym, const u8 *len, int lane)
 {
+    for (int k = lane; k < (1 << TB); k += 64) tab[k] = 0xFFFFu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int first_code[16], first_idx[16];
+    {
+        int code = 0, idx = 0;
+        for (int l = 1; l < 16; l++) {
+            first_code[l] = code;
+            first_idx[l] = idx;
+            code = (code + count[l]) << 1;
+            idx += count[l];
+        }
+        first_code[0] = first_idx[0] = 0;
+    }
+    int nsym = 0;
+    for (int l = 1; l < 16; l++) nsym += count[l];
+    for (int p = lane; p < nsym; p += 64) {
+        const int s = sym[p], l = len[s];
+        if (l > TB) continue;
+        const u32 code = (u32)(first_code[l] + (p - first_idx[l]));
+        const u32 rev = __brev(code) >> (32 - l);
+        for (u32 k = rev; k < (1u << TB); k += 1u << l) tab[k] = (u16)((s << 4) | l);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one symbol: table hit, or the bit-serial canonical walk for codes longer than the table (the reader holds > 32 bits)
+template <int TB>
+__device__ __forceinline__ int png_decode_sym(BitReader &r, const u16 *tab, const u16 *count, const u16 *sym)
+{
+    const u32 e = sld16(tab + r.peek(TB));
+    if (e != 0xFFFFu) {
+        r.drop((int)(e & 15u));
+        return (int)(e >> 4);
+    }
     int code = 0, first = 0, index = 0;
+    unsigned long long b = r.bb;
     for (int l = 1; l < 16; l++) {
-        code |= (int)r.bits(1);
-        const int c = h.count[l];
-        if (code - c < first) return h.sym[index + (code - first)];
+        code |= (int)(b & 1ull);
+        b >>= 1;
+        const int c = (int)sld16(count + l);
+        if (code - c < first) {
+            r.drop(l);
+            return (int)sld16(sym + index + (code - first));
+        }
         index += c;
         first += c;
         first <<= 1;
@@ -134,197 +206,409 @@ __device__ __forceinline__ int paeth(int a, int b, int c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// inflate the zlib stream of the file's IDAT chunks into out[0..cap); returns bytes written or a negative status
-__device__ long long inflate_idat(IdatReader &r, u8 *out, long long cap, u16 *lds /* >= 16+288+16+32 u16 + 320 bytes */)
+__device__ __forceinline__ u32 wave_sum(u32 v)
 {
-    Huff lc, dc;
-    lc.count = lds; lc.sym = lds + 16;
-    dc.count = lds + 16 + 288; dc.sym = lds + 16 + 288 + 16;
-    u8 *lens = (u8 *)(lds + 16 + 288 + 16 + 32);
-    const u32 cmf = r.byte(), flg = r.byte(); // RFC 1950: CM = 8, no preset dictionary, header check
-    if ((cmf & 15u) != 8u || (flg & 32u) || ((cmf << 8) | flg) % 31u) return -PNG_E_STREAM;
-    long long n = 0;
-    int last;
-    do {
-        last = (int)r.bits(1);
-        const int type = (int)r.bits(2);
-        if (r.err) return -r.err;
-        if (type == 0) { // stored
-            r.bitbuf = 0; r.bitcnt = 0;
-            u32 len = r.byte(); len |= r.byte() << 8;
-            u32 nlen = r.byte(); nlen |= r.byte() << 8;
-            if ((len ^ 0xFFFFu) != nlen) return -PNG_E_STREAM;
-            if (n + len > cap) return -PNG_E_SIZE;
-            for (u32 i = 0; i < len; i++) out[n++] = (u8)r.byte();
-        } else if (type == 1 || type == 2) {
-            if (type == 1) { // fixed codes (RFC 1951 3.2.6)
-                for (int i = 0; i < 144; i++) lens[i] = 8;
-                for (int i = 144; i < 256; i++) lens[i] = 9;
-                for (int i = 256; i < 280; i++) lens[i] = 7;
-                for (int i = 280; i < 288; i++) lens[i] = 8;
-                huff_build(lc, lens, 288);
-                for (int i = 0; i < 30; i++) lens[i] = 5;
-                huff_build(dc, lens, 30);
-            } else { // dynamic codes (3.2.7)
-                const int nlen = (int)r.bits(5) + 257, ndist = (int)r.bits(5) + 1, ncode = (int)r.bits(4) + 4;
-                if (nlen > 286 || ndist > 30) return -PNG_E_HUFF;
-                for (int i = 0; i < 19; i++) lens[i] = 0;
-                for (int i = 0; i < ncode; i++) lens[k_clen_order[i]] = (u8)r.bits(3);
-                if (huff_build(lc, lens, 19) != 0) return -PNG_E_HUFF; // the code-length code must be complete
-                int idx = 0;
-                while (idx < nlen + ndist) {
-                    int sym = huff_decode(r, lc);
-                    if (sym < 0 || r.err) return -PNG_E_HUFF;
-                    if (sym < 16) {
-                        lens[idx++] = (u8)sym;
-                    } else {
-                        int prev = 0, rep;
-                        if (sym == 16) {
-                            if (idx == 0) return -PNG_E_HUFF;
-                            prev = lens[idx - 1];
-                            rep = 3 + (int)r.bits(2);
-                        } else if (sym == 17) {
-                            rep = 3 + (int)r.bits(3);
-                        } else {
-                            rep = 11 + (int)r.bits(7);
-                        }
-                        if (idx + rep > nlen + ndist) return -PNG_E_HUFF;
-                        while (rep--) lens[idx++] = (u8)prev;
-                    }
-                }
-                if (lens[256] == 0) return -PNG_E_HUFF; // no end-of-block code
-                // the distance lengths follow the literal/length ones in the same array
-                int e = huff_build(dc, lens + nlen, ndist);
-                if (e < 0 || (e > 0 && ndist - dc.count[0] != 1)) return -PNG_E_HUFF;
-                e = huff_build(lc, lens, nlen);
-                if (e < 0 || (e > 0 && nlen - lc.count[0] != 1)) return -PNG_E_HUFF;
-            }
-            while (true) {
-                int sym = huff_decode(r, lc);
-                if (sym < 0 || r.err) return -PNG_E_HUFF;
-                if (sym < 256) {
-                    if (n >= cap) return -PNG_E_SIZE;
-                    out[n++] = (u8)sym;
-                } else if (sym == 256) {
-                    break;
-                } else {
-                    sym -= 257;
-                    if (sym >= 29) return -PNG_E_HUFF;
-                    const int len = k_len_base[sym] + (int)r.bits(k_len_extra[sym]);
-                    const int ds = huff_decode(r, dc);
-                    if (ds < 0 || ds >= 30) return -PNG_E_HUFF;
-                    const long long dist = (long long)k_dist_base[ds] + (long long)r.bits(k_dist_extra[ds]);
-                    if (dist > n) return -PNG_E_STREAM;
-                    if (n + len > cap) return -PNG_E_SIZE;
-                    for (int i = 0; i < len; i++, n++) out[n] = out[n - dist]; // may overlap: byte by byte
-                }
-            }
-        } else {
-            return -PNG_E_STREAM;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// What happens to scanline `y` once the inflate has produced it: Adler-32 of its filtered bytes, the filter reversed into
+// cur[] (prev[] = the unfiltered line above), the samples converted into the outputs.  Returns a status.
+struct RowSink {
+    const PngJobs *j;
+    int fidx, bpp, depth, rowb, W, H, C;
+    u32 a1, a2; // Adler-32 state
+};
+
+// Average (3) and Paeth (4): byte recurrences along the line.  The BPP byte positions of a pixel are BPP independent
+// chains (a byte depends on the byte BPP to its left): lane c walks chain c, the other lanes idle.  The operands that do not
+// depend on the recurrence (the filtered byte, the byte above) are fetched four steps at a time.
+__device__ __noinline__ void png_unfilter_serial(int ft, int bpp, const u8 *ring, u32 rs, int nb, const u8 *prev, u8 *cur,
+                                                 bool have_prev, int lane)
+{
+    if (lane >= bpp) return;
+    int left = 0, upleft = 0;
+    int i = lane;
+    for (; i + 3 * bpp < nb; i += 4 * bpp) {
+        int f[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            f[k] = ring[(rs + 1 + i + k * bpp) & (PNG_RING - 1)];
+            b[k] = have_prev ? prev[i + k * bpp] : 0;
         }
-    } while (!last);
-    return r.err ? -(long long)r.err : n;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int v = (ft == 3) ? (f[k] + ((left + b[k]) >> 1)) & 255 : (f[k] + paeth(left, b[k], upleft)) & 255;
+            cur[i + k * bpp] = (u8)v;
+            left = v;
+            upleft = b[k];
+        }
+    }
+    for (; i < nb; i += bpp) {
+        const int f = ring[(rs + 1 + i) & (PNG_RING - 1)];
+        const int b = have_prev ? prev[i] : 0;
+        const int v = (ft == 3) ? (f + ((left + b) >> 1)) & 255 : (f + paeth(left, b, upleft)) & 255;
+        cur[i] = (u8)v;
+        left = v;
+        upleft = b;
+    }
+}
+
+// (not inlined: the symbol loop around its call sites must stay small enough for the instruction cache)
+__device__ __noinline__ int png_row(RowSink &s, const u8 *ring, int y, const u8 *prev, u8 *cur, int lane)
+{
+    const u32 rs = (u32)((long long)y * s.rowb); // position of the filter byte in the stream (mod ring)
+    const int nb = s.rowb - 1, bpp = s.bpp;
+    const bool have_prev = y > 0;
+    // ---- Adler-32 (RFC 1950) of the rowb filtered bytes: a1' = a1 + sum b, a2' = a2 + n a1 + sum (n - i) b_i
+    {
+        u32 sb = 0, sw = 0;
+        for (int i = lane; i < s.rowb; i += 64) {
+            const u32 b = ring[(rs + i) & (PNG_RING - 1)];
+            sb += b;
+            sw += (u32)(s.rowb - i) * b; // <= 16385 * 255 per term, <= 257 terms per lane: fits 32 bits
+        }
+        sb = wave_sum(sb);
+        // sw can reach 64 * 257 * 16385 * 255 > 2^32 summed over the wave: reduce per lane first
+        sw = wave_sum(sw % 65521u);
+        s.a2 = (u32)(((unsigned long long)s.a2 + (unsigned long long)s.rowb * s.a1 + sw) % 65521ull);
+        s.a1 = (s.a1 + sb) % 65521u;
+    }
+    const int ft = (int)sld8(ring + (rs & (PNG_RING - 1)));
+    if (ft == 0) {
+        for (int i = lane; i < nb; i += 64) cur[i] = ring[(rs + 1 + i) & (PNG_RING - 1)];
+    } else if (ft == 2) {
+        for (int i = lane; i < nb; i += 64) cur[i] = (u8)(ring[(rs + 1 + i) & (PNG_RING - 1)] + (have_prev ? prev[i] : 0));
+    } else if (ft == 1) {
+        // Sub: per byte position of the pixel a running sum along the line = a scan: every lane sums a run of pixels, the
+        // wave scans the lane totals, every lane adds its offset
+        const int npx = (nb + bpp - 1) / bpp, per = (npx + 63) / 64;
+        const int p0 = lane * per, p1 = min(npx, p0 + per);
+        u32 tot[3] = {0, 0, 0}, pre[3];
+        for (int p = p0; p < p1; p++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { // (static indices: the sums stay in registers)
+                const int i = p * bpp + c;
+                if (c < bpp && i < nb) tot[c] += ring[(rs + 1 + i) & (PNG_RING - 1)];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            u32 v = tot[c];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 t = __shfl_up(v, off);
+                if (lane >= off) v += t;
+            }
+            pre[c] = v - tot[c]; // exclusive
+        }
+        for (int p = p0; p < p1; p++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int i = p * bpp + c;
+                if (c < bpp && i < nb) {
+                    pre[c] += ring[(rs + 1 + i) & (PNG_RING - 1)];
+                    cur[i] = (u8)pre[c];
+                }
+            }
+        }
+    } else if (ft == 3 || ft == 4) {
+        png_unfilter_serial(ft, bpp, ring, rs, nb, prev, cur, have_prev, lane);
+    } else {
+        return PNG_E_FILTER;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- samples -> outputs (all lanes)
+    const PngJobs &j = *s.j;
+    const size_t npix = (size_t)s.H * s.W;
+    if (j.out_u8) {
+        u8 *o = j.out_u8 + ((size_t)s.fidx * npix + (size_t)y * s.W) * j.C;
+        for (int i = lane; i < s.W * j.C; i += 64) o[i] = cur[i];
+    }
+    if (j.disp) {
+        float *d = j.disp + (size_t)s.fidx * npix + (size_t)y * s.W;
+        u8 *v = j.valid ? j.valid + (size_t)s.fidx * npix + (size_t)y * s.W : nullptr;
+        for (int x = lane; x < s.W; x += 64) {
+            const u8 *p = cur + x * bpp;
+            const u32 smp = s.depth == 16 ? (((u32)p[0] << 8) | p[1]) : p[0]; // PNG samples are big-endian
+            const float val = __fmul_rn((float)smp, j.scale);                 // exact for scale = 2^-8: what `img / 256.0` gives
+            d[x] = val;
+            if (v) v[x] = val > 0.0f ? 1 : 0;
+        }
+    }
+    return PNG_OK;
 }
 
 __global__ void __launch_bounds__(64) png_decode_kernel(PngJobs j)
 {
-    __shared__ u16 tables[16 + 288 + 16 + 32 + 160];
-    __shared__ int s_status, s_bpp, s_depth;
+    extern __shared__ __attribute__((aligned(16))) u8 png_lds[];
+    PngLds L;
+    {
+        u8 *p = png_lds;
+        L.in = p; p += PNG_IN_SZ;
+        L.ring = p; p += PNG_RING;
+        L.row[0] = p; p += PNG_ROWMAX;
+        L.row[1] = p; p += PNG_ROWMAX;
+        L.tab_l = (u16 *)p; p += (1 << PNG_LBITS) * 2;
+        L.tab_d = (u16 *)p; p += (1 << PNG_DBITS) * 2;
+        L.cnt_l = (u16 *)p; p += 32;
+        L.sym_l = (u16 *)p; p += 288 * 2;
+        L.cnt_d = (u16 *)p; p += 32;
+        L.sym_d = (u16 *)p; p += 32 * 2;
+        L.lens = p;
+    }
     const int fidx = blockIdx.x, lane = threadIdx.x;
     const u8 *f = j.blob + j.offs[fidx];
     const long long n = j.offs[fidx + 1] - j.offs[fidx];
-    u8 *raw = j.raw + (size_t)fidx * j.raw_stride;
-    if (lane == 0) {
-        int st = PNG_OK, bpp = 0, depth = 0;
-        do {
-            if (n < 8 + 25 + 12 || f[0] != 0x89 || f[1] != 'P' || f[2] != 'N' || f[3] != 'G' || f[4] != 13 || f[5] != 10 ||
-                f[6] != 26 || f[7] != 10) { st = PNG_E_SIG; break; }
-            IdatReader r;
-            r.f = f; r.n = n; r.err = 0; r.bitbuf = 0; r.bitcnt = 0; r.cache = 0; r.cache_a = ~0ull;
-            if (r.be32(8) != 13 || r.be32(12) != 0x49484452u) { st = PNG_E_IHDR; break; } // "IHDR"
-            const u32 w = r.be32(16), h = r.be32(20);
-            depth = f[24];
-            const int ctype = f[25], comp = f[26], filt = f[27], inter = f[28];
-            if (comp != 0 || filt != 0 || inter != 0 || !((ctype == 0 && (depth == 8 || depth == 16)) || (ctype == 2 && depth == 8))) {
-                st = PNG_E_UNSUPPORTED; break;
-            }
-            const int ch = ctype == 2 ? 3 : 1;
-            if ((int)w != j.W || (int)h != j.H || ch != j.C) { st = PNG_E_SIZE; break; }
-            bpp = ch * depth / 8;
-            const long long rowb = 1 + (long long)w * bpp, need = rowb * h;
-            if ((size_t)need > j.raw_stride) { st = PNG_E_SIZE; break; }
-            r.pos = r.end = 8 + 8 + 13; // "end of a payload": the IHDR data; next_chunk() skips its CRC
-            const long long got = inflate_idat(r, raw, need, tables);
-            if (got < 0) { st = (int)-got; break; }
-            if (got != need) { st = PNG_E_SIZE; break; }
-            // reverse the scanline filters in place (PNG 9.2): byte recurrences along x and y
-            for (u32 y = 0; y < h && st == PNG_OK; y++) {
-                u8 *cur = raw + y * rowb + 1;
-                const u8 *up = y ? raw + (y - 1) * rowb + 1 : nullptr;
-                const int ft = cur[-1];
-                const long long nb = rowb - 1;
-                switch (ft) {
-                case 0: break;
-                case 1:
-                    for (long long i = bpp; i < nb; i++) cur[i] = (u8)(cur[i] + cur[i - bpp]);
-                    break;
-                case 2:
-                    if (up) for (long long i = 0; i < nb; i++) cur[i] = (u8)(cur[i] + up[i]);
-                    break;
-                case 3:
-                    for (long long i = 0; i < nb; i++) {
-                        const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
-                        cur[i] = (u8)(cur[i] + ((a + b) >> 1));
-                    }
-                    break;
-                case 4:
-                    for (long long i = 0; i < nb; i++) {
-                        const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
-                        cur[i] = (u8)(cur[i] + paeth(a, b, c));
-                    }
-                    break;
-                default: st = PNG_E_FILTER;
+    u8 *z = j.zcat + j.zoffs[fidx];
+    int st = PNG_OK;
+    auto be32 = [&](long long p) -> u32 {
+        return (u32)__builtin_amdgcn_readfirstlane((int)(((u32)f[p] << 24) | ((u32)f[p + 1] << 16) | ((u32)f[p + 2] << 8) | (u32)f[p + 3]));
+    };
+    do {
+        if (n < 8 + 25 + 12 || f[0] != 0x89 || f[1] != 'P' || f[2] != 'N' || f[3] != 'G' || f[4] != 13 || f[5] != 10 || f[6] != 26 ||
+            f[7] != 10) { st = PNG_E_SIG; break; }
+        if (be32(8) != 13 || be32(12) != 0x49484452u) { st = PNG_E_IHDR; break; } // "IHDR"
+        const u32 w = be32(16), h = be32(20);
+        const int depth = __builtin_amdgcn_readfirstlane(f[24]), ctype = __builtin_amdgcn_readfirstlane(f[25]);
+        const int comp = __builtin_amdgcn_readfirstlane(f[26]), filt = __builtin_amdgcn_readfirstlane(f[27]), inter = __builtin_amdgcn_readfirstlane(f[28]);
+        if (comp != 0 || filt != 0 || inter != 0 || !((ctype == 0 && (depth == 8 || depth == 16)) || (ctype == 2 && depth == 8))) {
+            st = PNG_E_UNSUPPORTED; break;
+        }
+        const int ch = ctype == 2 ? 3 : 1;
+        if ((int)w != j.W || (int)h != j.H || ch != j.C) { st = PNG_E_SIZE; break; }
+        const int bpp = ch * depth / 8;
+        const long long rowb = 1 + (long long)w * bpp, need = rowb * h;
+        if (rowb > PNG_ROWMAX) { st = PNG_E_UNSUPPORTED; break; }
+        // ---- concatenate the IDAT payloads (all lanes copy, the chunk walk is uniform)
+        u32 zlen = 0;
+        {
+            long long p = 8 + 8 + 13 + 4; // behind IHDR and its CRC
+            bool end = false;
+            while (p + 12 <= n && !end) {
+                const u32 len = be32(p), type = be32(p + 4);
+                if (p + 12 + (long long)len > n) { st = PNG_E_TRUNC; break; }
+                if (type == 0x49444154u) { // "IDAT"
+                    for (u32 q = (u32)lane; q < len; q += 64) z[zlen + q] = f[p + 8 + q];
+                    zlen += len;
+                } else if (type == 0x49454E44u) { // "IEND"
+                    end = true;
                 }
+                p += 12 + (long long)len;
             }
-        } while (false);
-        s_status = st; s_bpp = bpp; s_depth = depth;
-        j.status[fidx] = st;
-    }
-    __syncthreads();
-    if (s_status != PNG_OK) return;
-    // all lanes: samples -> outputs
-    const int W = j.W, H = j.H, bpp = s_bpp;
-    const long long rowb = 1 + (long long)W * bpp;
-    const size_t npix = (size_t)H * W;
-    if (j.out_u8) {
-        u8 *o = j.out_u8 + (size_t)fidx * npix * j.C;
-        for (size_t i = lane; i < npix * j.C; i += 64) {
-            const size_t y = i / ((size_t)W * j.C), k = i % ((size_t)W * j.C);
-            o[i] = raw[y * rowb + 1 + k];
+            if (st != PNG_OK) break;
+            if (zlen < 6) { st = PNG_E_TRUNC; break; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the stream is read back (by other lanes) through the L1
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-    }
-    if (j.disp) {
-        float *d = j.disp + (size_t)fidx * npix;
-        u8 *v = j.valid ? j.valid + (size_t)fidx * npix : nullptr;
-        for (size_t i = lane; i < npix; i += 64) {
-            const size_t y = i / W, x = i % W;
-            const u8 *p = raw + y * rowb + 1 + x * bpp;
-            const u32 s = s_depth == 16 ? (((u32)p[0] << 8) | p[1]) : p[0]; // PNG samples are big-endian
-            const float val = __fmul_rn((float)s, j.scale); // exact for scale = 2^-8: what `img / 256.0` gives
-            d[i] = val;
-            if (v) v[i] = val > 0.0f ? 1 : 0;
-        }
-    }
+        BitReader r;
+        r.z = z; r.zlen = zlen; r.in = L.in;
+        r.init(lane);
+        const u32 cmf = r.bits(8, lane), flg = r.bits(8, lane); // RFC 1950: CM = 8, no preset dictionary, header check
+        if ((cmf & 15u) != 8u || (flg & 32u) || ((cmf << 8) | flg) % 31u) { st = PNG_E_STREAM; break; }
+        RowSink sink;
+        sink.j = &j; sink.fidx = fidx; sink.bpp = bpp; sink.depth = depth; sink.rowb = (int)rowb; sink.W = j.W; sink.H = j.H; sink.C = j.C;
+        sink.a1 = 1; sink.a2 = 0;
+        u32 wpos = 0; // bytes inflated so far (need < 2^31)
+        int rows_done = 0;
+        auto rows = [&]() { // scanlines completed by the bytes produced so far
+            while (st == PNG_OK && rows_done < (int)h && wpos >= (u32)(rows_done + 1) * (u32)rowb) {
+                st = __builtin_amdgcn_readfirstlane(png_row(sink, L.ring, rows_done, L.row[(rows_done + 1) & 1], L.row[rows_done & 1], lane));
+                rows_done++;
+            }
+        };
+        int last;
+        u32 next_row_end = (u32)rowb;
+        do {
+            last = (int)r.bits(1, lane);
+            next_row_end = (u32)(rows_done + 1) * (u32)rowb;
+            const int type = (int)r.bits(2, lane);
+            if (type == 0) { // stored: skip to the byte boundary, LEN, NLEN, bytes
+                r.drop(r.bc & 7);
+                const u32 len = r.bits(16, lane), nlen = r.bits(16, lane);
+                if ((len ^ 0xFFFFu) != nlen) { st = PNG_E_STREAM; break; }
+                if ((long long)wpos + len > need) { st = PNG_E_SIZE; break; }
+                for (u32 i = 0; i < len && st == PNG_OK; i++) {
+                    const u32 b = r.bits(8, lane);
+                    L.ring[wpos & (PNG_RING - 1)] = (u8)b;
+                    wpos++;
+                    if ((i & 63u) == 63u || i + 1 == len) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        rows();
+                    }
+                }
+            } else if (type == 1 || type == 2) {
+                if (type == 1) { // fixed codes (RFC 1951 3.2.6)
+                    for (int i = lane; i < 288; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane == 0) png_huff_build(L.cnt_l, L.sym_l, L.lens, 288);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    png_table_build<PNG_LBITS>(L.tab_l, L.cnt_l, L.sym_l, L.lens, lane);
+                    for (int i = lane; i < 30; i += 64) L.lens[i] = 5;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane == 0) png_huff_build(L.cnt_d, L.sym_d, L.lens, 30);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    png_table_build<PNG_DBITS>(L.tab_d, L.cnt_d, L.sym_d, L.lens, lane);
+                } else { // dynamic codes (3.2.7)
+                    const int nlen = (int)r.bits(5, lane) + 257, ndist = (int)r.bits(5, lane) + 1, ncode = (int)r.bits(4, lane) + 4;
+                    if (nlen > 286 || ndist > 30) { st = PNG_E_HUFF; break; }
+                    for (int i = lane; i < 320; i += 64) L.lens[i] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int i = 0; i < ncode; i++) {
+                        const u32 v = r.bits(3, lane);
+                        if (lane == 0) L.lens[k_clen_order[i]] = (u8)v;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // the code-length code (19 symbols, <= 7 bits) is walked bit-serially from its canonical tables; its
+                    // tables share the literal/length arrays, which are rebuilt below
+                    int e = 0;
+                    if (lane == 0) e = png_huff_build(L.cnt_l, L.sym_l, L.lens, 19);
+                    e = __builtin_amdgcn_readfirstlane(e);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (e != 0) { st = PNG_E_HUFF; break; } // the code-length code must be complete
+                    // (the decoded lengths go to lens[32 ..]: lens[0 .. 19) still holds the code-length code's own lengths)
+                    u8 *cl = L.lens + 32;
+                    int idx = 0;
+                    while (idx < nlen + ndist) {
+                        r.ensure(lane);
+                        int sym = -1;
+                        {
+                            int code = 0, first = 0, index = 0;
+                            unsigned long long b = r.bb;
+                            for (int l = 1; l < 8; l++) {
+                                code |= (int)(b & 1ull);
+                                b >>= 1;
+                                const int c = (int)sld16(L.cnt_l + l);
+                                if (code - c < first) { sym = (int)sld16(L.sym_l + index + (code - first)); r.drop(l); break; }
+                                index += c; first += c; first <<= 1; code <<= 1;
+                            }
+                        }
+                        if (sym < 0) { st = PNG_E_HUFF; break; }
+                        if (sym < 16) {
+                            if (lane == 0) cl[idx] = (u8)sym;
+                            idx++;
+                        } else {
+                            int prev = 0, rep;
+                            if (sym == 16) {
+                                if (idx == 0) { st = PNG_E_HUFF; break; }
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                prev = (int)sld8(cl + idx - 1);
+                                rep = 3 + (int)r.bits(2, lane);
+                            } else if (sym == 17) {
+                                rep = 3 + (int)r.bits(3, lane);
+                            } else {
+                                rep = 11 + (int)r.bits(7, lane);
+                            }
+                            if (idx + rep > nlen + ndist) { st = PNG_E_HUFF; break; }
+                            for (int q = lane; q < rep; q += 64) cl[idx + q] = (u8)prev;
+                            idx += rep;
+                        }
+                    }
+                    if (st != PNG_OK) break;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (sld8(cl + 256) == 0) { st = PNG_E_HUFF; break; } // no end-of-block code
+                    // the distance lengths follow the literal/length ones in the same array
+                    int ed = 0, el = 0;
+                    if (lane == 0) {
+                        ed = png_huff_build(L.cnt_d, L.sym_d, cl + nlen, ndist);
+                        if (ed > 0 && ndist - L.cnt_d[0] == 1) ed = 0; // one distance code of any length is allowed (RFC 1951 3.2.7)
+                        el = png_huff_build(L.cnt_l, L.sym_l, cl, nlen);
+                        if (el > 0 && nlen - L.cnt_l[0] == 1) el = 0;
+                    }
+                    ed = __builtin_amdgcn_readfirstlane(ed);
+                    el = __builtin_amdgcn_readfirstlane(el);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (ed != 0 || el != 0) { st = PNG_E_HUFF; break; }
+                    png_table_build<PNG_LBITS>(L.tab_l, L.cnt_l, L.sym_l, cl, lane);
+                    png_table_build<PNG_DBITS>(L.tab_d, L.cnt_d, L.sym_d, cl + nlen, lane);
+                }
+                while (st == PNG_OK) {
+                    r.ensure(lane);
+                    int sym = png_decode_sym<PNG_LBITS>(r, L.tab_l, L.cnt_l, L.sym_l);
+                    if (sym < 0) { st = PNG_E_HUFF; break; }
+                    if (sym < 256) {
+                        if ((long long)wpos >= need) { st = PNG_E_SIZE; break; }
+                        L.ring[wpos & (PNG_RING - 1)] = (u8)sym; // (every lane stores the same byte: no divergent region)
+                        wpos++;
+                    } else if (sym == 256) {
+                        break;
+                    } else {
+                        sym -= 257;
+                        if (sym >= 29) { st = PNG_E_HUFF; break; }
+                        const int lx = __builtin_amdgcn_readfirstlane((int)k_len_extra[sym]);
+                        const int len = __builtin_amdgcn_readfirstlane((int)k_len_base[sym]) + (int)r.peek(lx);
+                        r.drop(lx);
+                        r.ensure(lane);
+                        const int ds = png_decode_sym<PNG_DBITS>(r, L.tab_d, L.cnt_d, L.sym_d);
+                        if (ds < 0 || ds >= 30) { st = PNG_E_HUFF; break; }
+                        const int dx = __builtin_amdgcn_readfirstlane((int)k_dist_extra[ds]);
+                        const u32 dist = (u32)__builtin_amdgcn_readfirstlane((int)k_dist_base[ds]) + r.peek(dx);
+                        r.drop(dx);
+                        if (dist > wpos) { st = PNG_E_STREAM; break; }
+                        if ((long long)wpos + len > need) { st = PNG_E_SIZE; break; }
+                        // all lanes copy: a match that overlaps itself repeats with period dist, so every byte's source
+                        // lies in [wpos - dist, wpos), written before this copy began
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (dist >= (u32)len) {
+                            for (int i = lane; i < len; i += 64) L.ring[(wpos + (u32)i) & (PNG_RING - 1)] = L.ring[(wpos - dist + (u32)i) & (PNG_RING - 1)];
+                        } else {
+                            for (int i = lane; i < len; i += 64)
+                                L.ring[(wpos + (u32)i) & (PNG_RING - 1)] = L.ring[(wpos - dist + (u32)i % dist) & (PNG_RING - 1)];
+                        }
+                        wpos += (u32)len;
+                    }
+                    if (wpos >= next_row_end) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        rows();
+                        next_row_end = (u32)(rows_done + 1) * (u32)rowb;
+                        if (r.overrun()) { st = PNG_E_TRUNC; break; } // (past the end the window holds zeros: the size checks end the loop)
+                    }
+                }
+            } else {
+                st = PNG_E_STREAM;
+            }
+            if (st == PNG_OK && r.overrun()) st = PNG_E_TRUNC;
+        } while (!last && st == PNG_OK);
+        if (st != PNG_OK) break;
+        if ((long long)wpos != need || rows_done != (int)h) { st = PNG_E_SIZE; break; }
+        // the stream ends with the Adler-32 of the inflated bytes, big-endian, on a byte boundary (RFC 1950)
+        r.drop(r.bc & 7);
+        u32 want = 0;
+        for (int q = 0; q < 4; q++) want = (want << 8) | r.bits(8, lane);
+        if (r.overrun()) { st = PNG_E_TRUNC; break; }
+        if (want != ((sink.a2 << 16) | sink.a1)) { st = PNG_E_ADLER; break; }
+    } while (false);
+    if (lane == 0) j.status[fidx] = st;
 }
 
-int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const long long *offs_dev, int H, int W, int C, int max_bpp,
-                       u8 *raw_scratch, size_t raw_stride, float scale, float *disp, u8 *valid, u8 *out_u8, int *status_dev)
+int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const long long *offs_dev, int H, int W, int C, u8 *zcat,
+                       const long long *zoffs_dev, float scale, float *disp, u8 *valid, u8 *out_u8, int *status_dev)
 {
-    (void)max_bpp;
     PngJobs j;
-    j.blob = blob_dev; j.offs = offs_dev; j.raw = raw_scratch; j.raw_stride = raw_stride; j.disp = disp; j.valid = valid;
+    j.blob = blob_dev; j.offs = offs_dev; j.zcat = zcat; j.zoffs = zoffs_dev; j.disp = disp; j.valid = valid;
     j.out_u8 = out_u8; j.status = status_dev; j.H = H; j.W = W; j.C = C; j.scale = scale;
-    png_decode_kernel<<<dim3(n_files), 64, 0, ctx->stream>>>(j);
+    const size_t lds = PNG_IN_SZ + PNG_RING + 2 * PNG_ROWMAX + ((1 << PNG_LBITS) + (1 << PNG_DBITS)) * 2 + 32 + 576 + 32 + 64 + 384;
+    static bool attr_set[VPPX_MAX_DEVICES] = {};
+    if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)]) {
+        VPPX_HIP(hipFuncSetAttribute((const void *)png_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)] = true;
+    }
+    png_decode_kernel<<<dim3(n_files), 64, lds, ctx->stream>>>(j);
     VPPX_CHECK_LAUNCH();
     return 0;
 }

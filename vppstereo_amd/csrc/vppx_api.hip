@@ -1235,16 +1235,22 @@ extern "C" int vppx_png_decode_dev(vppx_ctx *ctx, int n_files, const uint8_t *bl
     }
     for (int i = 0; i < n_files; i++)
         if (offsets[i + 1] < offsets[i]) { vppx_set_error("vppx_png_decode: offsets must be non-decreasing"); return VPPX_E_INVALID_ARG; }
-    const size_t raw_stride = ((size_t)H * (1 + (size_t)W * C * 2) + 15) & ~(size_t)15; // up to 16-bit samples
-    u8 *raw;
+    if (1 + (size_t)W * C * 2 > 16384) { vppx_set_error("vppx_png_decode: scanlines longer than 16 KB are not supported"); return VPPX_E_UNSUPPORTED; }
+    // scratch for the concatenated IDAT payloads: file i's zlib stream starts 16-byte aligned at zoffs[i] (<= its file size)
+    ctx->png_offs_host.assign(offsets, offsets + n_files + 1);
+    size_t ztot = 0;
+    for (int i = 0; i < n_files; i++) {
+        ctx->png_offs_host.push_back((long long)ztot);
+        ztot += (((size_t)(offsets[i + 1] - offsets[i])) + 15 + 16) & ~(size_t)15;
+    }
+    u8 *zcat;
     long long *offs_d;
     int *st_d;
-    if ((rc = ws_get(ctx, WS_PNG_RAW, raw_stride * n_files, &raw))) return rc;
-    if ((rc = ws_get(ctx, WS_PNG_OFFS, (size_t)n_files + 1, &offs_d))) return rc;
+    if ((rc = ws_get(ctx, WS_PNG_RAW, ztot + 16, &zcat))) return rc;
+    if ((rc = ws_get(ctx, WS_PNG_OFFS, (size_t)2 * n_files + 1, &offs_d))) return rc;
     if (!status && (rc = ws_get(ctx, WS_PNG_STATUS, (size_t)n_files, &st_d))) return rc;
-    ctx->png_offs_host.assign(offsets, offsets + n_files + 1);
-    VPPX_HIP(hipMemcpyAsync(offs_d, ctx->png_offs_host.data(), ((size_t)n_files + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
-    return handoff_png_decode(ctx, n_files, blob, offs_d, H, W, C, 2, raw, raw_stride, scale, disp, valid, out_u8, status ? status : st_d);
+    VPPX_HIP(hipMemcpyAsync(offs_d, ctx->png_offs_host.data(), ((size_t)2 * n_files + 1) * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    return handoff_png_decode(ctx, n_files, blob, offs_d, H, W, C, zcat, offs_d + n_files + 1, scale, disp, valid, out_u8, status ? status : st_d);
 }
 
 // ---------------------------------------------------------------------------------------

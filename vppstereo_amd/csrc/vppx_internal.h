@@ -91,7 +91,7 @@ enum WsSlot {
     WS_NHINTS,
     WS_HANDOFF_H,    // hints / valid at feature resolution (hand-off kernels)
     WS_HANDOFF_V,
-    WS_PNG_RAW,      // inflated scanlines of a batch of PNG files
+    WS_PNG_RAW,      // concatenated IDAT payloads of a batch of PNG files (the zlib streams)
     WS_PNG_OFFS,
     WS_PNG_STATUS,
     WS_NUM
@@ -300,8 +300,8 @@ int handoff_raft_corr_modulate(vppx_ctx *ctx, float *corr, const float *hints, c
 int handoff_kitti_decode(vppx_ctx *ctx, const uint16_t *png, size_t n, float *disp, u8 *valid);
 int handoff_pfm_decode(vppx_ctx *ctx, const u8 *raw, int H, int W, int channels, int little, float *out);
 // png_kernels.hip
-int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const long long *offs_dev, int H, int W, int C, int max_bpp,
-                       u8 *raw_scratch, size_t raw_stride, float scale, float *disp, u8 *valid, u8 *out_u8, int *status_dev);
+int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const long long *offs_dev, int H, int W, int C, u8 *zcat,
+                       const long long *zoffs_dev, float scale, float *disp, u8 *valid, u8 *out_u8, int *status_dev);
 
 // occ_kernels (in vpp_kernels.hip)
 int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,

@@ -226,7 +226,7 @@ class Engine:
         offs = np.zeros(n + 1, np.int64)
         for i, b in enumerate(files):
             offs[i + 1] = offs[i] + len(b)
-        blob = torch.frombuffer(bytearray(b"".join(files) + bytes(8)), dtype=torch.uint8).to(self.device)  # padded: aligned word reads
+        blob = torch.frombuffer(bytearray(b"".join(files)), dtype=torch.uint8).to(self.device)
         status = torch.empty((n,), dtype=torch.int32, device=self.device)
         disp = valid = out = None
         if want == "disp":
