@@ -300,3 +300,36 @@ def test_pipelining_with_an_inputs_ready_event_from_a_loader_stream():
     eng.synchronize()
     for i, out in got:
         assert torch.equal(out, want[i]), i
+
+
+def test_fused_kernels_soak_alone_and_next_to_competing_work():
+    """The lock-step hand-off under load: 60 back-to-back fused steps must all give the first step's bits, alone and with
+    bf16 GEMMs of a second stream competing for the CUs (which may slow the launches down or, at worst, trip the bounded
+    waits -- that would raise -- but never change a result silently).  Both fused kernels (8 and 16 pixels per wave)."""
+    import torch
+    D = 192
+    for ppw in (16, 8):
+        eng = _engine(VPPX_VERT=3, VPPX_V3_PPW=ppw)
+        b, args = _small_batch(eng, B=16, H=270, W=480, seed=40 + ppw)
+        ref = eng.vpp_rsgm(*args, seed=2, rsgm_kw=dict(dmax=D)).clone()
+        eng.synchronize()
+        assert eng.uses_vert() == 3 and eng.fused_pixels_per_wave() == ppw
+        out = torch.empty_like(ref)
+        for i in range(60):
+            eng.vpp_rsgm(*args, out=out, seed=2, rsgm_kw=dict(dmax=D))
+            if i % 6 == 5:
+                eng.synchronize()
+                assert torch.equal(out, ref), (ppw, i)
+        side = torch.cuda.Stream(device=eng.device)
+        a = torch.randn(4096, 4096, device=eng.device, dtype=torch.bfloat16)
+        for i in range(24):
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    a @ a
+            eng.vpp_rsgm(*args, out=out, seed=2, rsgm_kw=dict(dmax=D))
+            if i % 6 == 5:
+                eng.synchronize()
+                assert torch.equal(out, ref), (ppw, i)
+        torch.cuda.synchronize()
+        eng.status()
+        assert eng.uses_vert() == 3

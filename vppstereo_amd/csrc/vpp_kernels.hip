@@ -60,6 +60,8 @@ struct VppK {
     unsigned long long *frame_tot; // [B][2] {draws, hints}
     const u8 *rnd;       // [B][rnd_cap]
     size_t rnd_cap;
+    u32 *lwork;          // L pixels deferred to the second pass: {frame, y << 16 | x} per entry
+    int *lwork_cnt;      // their number
 };
 
 // ---------------------------------------------------------------------------------------
@@ -189,6 +191,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
 // 2. exclusive scan of the per-row draw counts (one block per frame)
 __global__ void __launch_bounds__(256) rowscan_kernel(VppK k, long long *n_hints_out)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && k.lwork_cnt) *k.lwork_cnt = 0; // work list of the L side's second pass (apply_l_heavy_kernel)
     __shared__ unsigned long long s_d[4], s_c[4];
     __shared__ unsigned long long s_run_d, s_run_c;
     const int f = blockIdx.x;
@@ -748,8 +751,10 @@ __global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
 // 4. L pixels (must run BEFORE apply_r_kernel: it replays R chains from the original R)
 // ---------------------------------------------------------------------------------------
 // one hint at (yy, xx) acting on L pixel (yp, xp)
+// `defer` != nullptr: the caller cannot afford the occluded-hint branch (it replays R sub-chains: ten times the work of a
+// plain blend, and one such lane holds its whole wave up); instead of taking it, set *defer and return.
 __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int xp, int yy, int xx, float gv, u8 (&L)[4],
-                                             const u8 *rnd_f)
+                                             const u8 *rnd_f, bool *defer = nullptr)
 {
     const int W = k.W, H = k.H;
     const size_t rowoff = ((size_t)f * H + yy) * W;
@@ -767,6 +772,10 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
             for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]);
             return true;
         } else if (!k.discard) {                                      // pyx:114-122
+            if (defer) {
+                *defer = true;
+                return false;
+            }
             if (k.interp) {
                 const int q0 = xd0 + xw;
                 int q1 = xd1 + xw;
@@ -808,6 +817,52 @@ __device__ __forceinline__ bool l_pixel_driven(const VppK &k, int f, int patch_a
     return k.frame_tot[2 * f + 1] * (unsigned long long)patch_area > (unsigned long long)k.H * k.W;
 }
 
+// The replay of one L pixel: the hints of its window in scan order.  Returns false when the pixel was deferred.
+template <int NWIN>
+__device__ __forceinline__ bool l_replay_pixel(const VppK &k, int f, int yp, int xp, unsigned long long mask, const float *gf,
+                                               const u8 *rnd_f, bool may_defer)
+{
+    constexpr int n = (NWIN - 1) / 2;
+    const int W = k.W, H = k.H;
+    u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
+    u8 L[4] = {0, 0, 0, 0};
+    for (int j = 0; j < k.C; j++) L[j] = px[j];
+    bool touched = false, defer = false;
+    while (mask) {
+        const int q = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int yy = yp - n + q / NWIN;
+        const int xx = k.direction ? xp - n + q % NWIN : xp + n - q % NWIN;
+        touched |= l_apply_hint(k, f, yp, xp, yy, xx, gf[(size_t)yy * W + xx], L, rnd_f, may_defer ? &defer : nullptr);
+        if (defer) return false;
+    }
+    if (touched)
+        for (int j = 0; j < k.C; j++) px[j] = L[j];
+    return true;
+}
+
+// the window of hint values around an L pixel as a bit mask in scan order (pyx:78,129)
+template <int NWIN>
+__device__ __forceinline__ unsigned long long l_window_mask(const VppK &k, const float *gf, int yp, int xp)
+{
+    constexpr int n = (NWIN - 1) / 2, NP = NWIN * NWIN;
+    const int W = k.W, H = k.H;
+    unsigned long long mask = 0;
+    float gw[NP];
+#pragma unroll
+    for (int wa = 0; wa < NWIN; wa++)
+#pragma unroll
+        for (int wb = 0; wb < NWIN; wb++) {
+            const int yy = yp - n + wa;
+            const int xx = k.direction ? xp - n + wb : xp + n - wb;
+            const bool in = yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
+            gw[wa * NWIN + wb] = in ? gf[(size_t)yy * W + xx] : 0.f;
+        }
+#pragma unroll
+    for (int q = 0; q < NP; q++) mask |= (gw[q] > 0) ? (1ull << q) : 0ull;
+    return mask;
+}
+
 template <int NWIN>
 __global__ void __launch_bounds__(64) apply_l_hint_kernel(VppK k)
 {
@@ -819,41 +874,40 @@ __global__ void __launch_bounds__(64) apply_l_hint_kernel(VppK k)
     const int cnt = k.row_count[(size_t)f * H + y];
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
     const float *gf = k.g + (size_t)f * H * W;
+    // With an occlusion mask, a pixel whose window holds an occluded hint replays R sub-chains (pyx:114-122): rare, ten
+    // times the work, and it would hold up the 63 other lanes of its wave.  Such pixels go to a work list and are replayed
+    // by apply_l_heavy_kernel, 64 of them per wave.
+    const bool may_defer = k.occ != nullptr && !k.discard && k.lwork != nullptr;
     for (int t = threadIdx.x; t < cnt * NP; t += 64) {
         const int i = t / NP, p = t % NP;
         const int a = p / NWIN, b = p % NWIN;
         const int hx = k.rec[rowoff + i].x;
         const int yp = y + a - n, xp = hx + b - n; // the patch pixel this thread stands for
         if (yp < 0 || yp > H - 1 || xp < 0 || xp > W - 1) continue;
-        unsigned long long mask = 0;
-        float gw[NP];
-#pragma unroll
-        for (int wa = 0; wa < NWIN; wa++)
-#pragma unroll
-            for (int wb = 0; wb < NWIN; wb++) {
-                const int yy = yp - n + wa;
-                const int xx = k.direction ? xp - n + wb : xp + n - wb; // bit order = scan order (pyx:78,129)
-                const bool in = yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
-                gw[wa * NWIN + wb] = in ? gf[(size_t)yy * W + xx] : 0.f;
-            }
-#pragma unroll
-        for (int q = 0; q < NP; q++) mask |= (gw[q] > 0) ? (1ull << q) : 0ull;
+        const unsigned long long mask = l_window_mask<NWIN>(k, gf, yp, xp);
         // this hint's own bit in that window; a later bit means another hint's thread owns the pixel
         const int my_bit = (2 * n - a) * NWIN + (k.direction ? 2 * n - b : b);
         if ((mask >> my_bit) >> 1) continue;
-        u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
-        u8 L[4] = {0, 0, 0, 0};
-        for (int j = 0; j < k.C; j++) L[j] = px[j];
-        bool touched = false;
-        while (mask) {
-            const int q = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int yy = yp - n + q / NWIN;
-            const int xx = k.direction ? xp - n + q % NWIN : xp + n - q % NWIN;
-            touched |= l_apply_hint(k, f, yp, xp, yy, xx, gf[(size_t)yy * W + xx], L, rnd_f);
+        if (!l_replay_pixel<NWIN>(k, f, yp, xp, mask, gf, rnd_f, may_defer)) {
+            const int slot = atomicAdd(k.lwork_cnt, 1);
+            k.lwork[2 * (size_t)slot] = (u32)f;
+            k.lwork[2 * (size_t)slot + 1] = ((u32)yp << 16) | (u32)xp;
         }
-        if (touched)
-            for (int j = 0; j < k.C; j++) px[j] = L[j];
+    }
+}
+
+// second pass of the sparse mapping: the deferred pixels, one thread each (grid-stride over the work list)
+template <int NWIN>
+__global__ void __launch_bounds__(64) apply_l_heavy_kernel(VppK k)
+{
+    const int cnt = *k.lwork_cnt;
+    for (int e = blockIdx.x * 64 + threadIdx.x; e < cnt; e += gridDim.x * 64) {
+        const int f = (int)k.lwork[2 * (size_t)e];
+        const u32 yx = k.lwork[2 * (size_t)e + 1];
+        const int yp = (int)(yx >> 16), xp = (int)(yx & 0xFFFFu);
+        const float *gf = k.g + (size_t)f * k.H * k.W;
+        const unsigned long long mask = l_window_mask<NWIN>(k, gf, yp, xp);
+        (void)l_replay_pixel<NWIN>(k, f, yp, xp, mask, gf, k.rnd + (size_t)f * k.rnd_cap, false);
     }
 }
 
@@ -1495,6 +1549,8 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     if ((rc = ws_get(ctx, WS_HINT_DENSE, npx, &k.dense))) return rc;
     if ((rc = ws_get(ctx, WS_HINT_X, npx, &k.rng))) return rc;
     k.rcnt = nullptr;
+    k.lwork = nullptr;
+    k.lwork_cnt = nullptr;
     k.rlist = nullptr;
     if ((rc = ws_get(ctx, WS_ROW_COUNT, (size_t)g.B * g.H, &k.row_count))) return rc;
     if ((rc = ws_get(ctx, WS_ROW_DRAWS, (size_t)g.B * g.H, &k.row_draws))) return rc;
@@ -1546,6 +1602,8 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     const int nblk = (int)(cap / LG);
     const u32 *tab;
     if ((rc = ensure_rand_table(ctx, nblk, &tab))) return rc;
+    if ((rc = ws_get(ctx, WS_LWORK, npx * 2, &k.lwork))) return rc; // (a pixel is deferred at most once)
+    if ((rc = ws_get(ctx, WS_LWORK_CNT, (size_t)4, &k.lwork_cnt))) return rc;
 
     compact_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
@@ -1559,6 +1617,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     dim3 grid((g.W + 255) / 256, g.H, g.B);
     if ((rc = ws_get(ctx, WS_RCNT, npx, &k.rcnt))) return rc;
     if ((rc = ws_get(ctx, WS_RLIST, npx * RLCAP, &k.rlist))) return rc;
+
     // The L side reads R only for occluded hints (pyx:114-122).  Without an occlusion mask the two sides are
     // independent: the (latency-bound) L kernels then run on the side stream next to the R list build + replay.
     // With a mask the L side replays R sub-chains from the pixels' hint lists and the ORIGINAL right image: when the
@@ -1580,6 +1639,10 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         ls = ctx->stream2;
     }
+    // pixels with an occluded hint in their window: second pass (from 8 frames per call on; for a single frame the extra
+    // launch costs more than the divergence it removes: 0.70 -> 0.77 ms per frame)
+    const bool two_pass = occ != nullptr && !k.discard && k.n <= 3 && g.B >= 8;
+    if (!two_pass) k.lwork = nullptr; // (rowscan_kernel has zeroed the work-list counter)
     switch (k.n) { // sparse frames (each frame picks one of the two mappings on the device)
     case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
     case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
@@ -1588,6 +1651,16 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     default: break;
     }
     VPPX_CHECK_LAUNCH();
+    if (two_pass) {
+        const dim3 hg((unsigned)(g.B * 64 < 4096 ? g.B * 64 : 4096));
+        switch (k.n) {
+        case 0: apply_l_heavy_kernel<1><<<hg, 64, 0, ls>>>(k); break;
+        case 1: apply_l_heavy_kernel<3><<<hg, 64, 0, ls>>>(k); break;
+        case 2: apply_l_heavy_kernel<5><<<hg, 64, 0, ls>>>(k); break;
+        default: apply_l_heavy_kernel<7><<<hg, 64, 0, ls>>>(k); break;
+        }
+        VPPX_CHECK_LAUNCH();
+    }
     switch (k.n) {
     case 0: apply_l_kernel<1><<<grid, 256, 0, ls>>>(k); break;
     case 1: apply_l_kernel<3><<<grid, 256, 0, ls>>>(k); break;

@@ -47,6 +47,8 @@ enum WsSlot {
     WS_FILLED_G,
     WS_GRAY_CTX,
     WS_RLIST,
+    WS_LWORK,        // L pixels whose window holds an occluded hint (second pass of the sparse L mapping)
+    WS_LWORK_CNT,
     WS_ROW_COUNT,
     WS_ROW_DRAWS,
     WS_ROW_BASE,
