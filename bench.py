@@ -571,13 +571,15 @@ def run_rank(args):
         sclk_mhz = sclk.mhz()
         valu = None
         if pmc and pmc.get("SQ_INSTS_VALU"):
-            # shader clock: sampled from sysfs during the timed region; else what the profile run measured
-            # (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / the kernel's duration in that run)
-            clk = sclk_mhz or pmc.get("sclk_mhz_profiled")
+            # shader clock of THIS kernel under load: GRBM_GUI_ACTIVE (shader-clock cycles per XCD, summed over the 8 XCDs)
+            # / 8 / the kernel's duration, both from the SQ pass of the committed profile; the sysfs DPM table sampled
+            # during the timed region only names the active level (its nominal MHz), so it is the fallback
+            clk = pmc.get("sclk_mhz_profiled") or sclk_mhz
             if clk:
                 floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (N_SIMD * clk * 1e6) * 1e3
                 valu = {"SQ_INSTS_VALU_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
-                        "simds": N_SIMD, "sclk_mhz": clk, "sclk_source": "sysfs pp_dpm_sclk during the timed region" if sclk_mhz else "profile run (GRBM_GUI_ACTIVE)",
+                        "simds": N_SIMD, "sclk_mhz": clk, "sclk_source": ("profile run: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration" if pmc.get("sclk_mhz_profiled")
+                                        else "sysfs pp_dpm_sclk level during the timed region"),
                         "issue_floor_ms": round(floor_ms, 3), "frac_of_issue_floor": round(floor_ms / agg_ms, 4),
                         "wave_cycles_active_issuewait_memwait": [pmc.get("sq_active_inst_any_frac_of_wave_cycles"),
                                                                  pmc.get("sq_wait_inst_any_frac_of_wave_cycles"),
@@ -597,7 +599,7 @@ def run_rank(args):
                              "convention, not a utilisation: see valu and hbm_frac_of_peak)",
                "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": round(we_ms, 4)} if fused else None),
                "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,
-               "sclk_mhz_during_timed_region": sclk_mhz,
+               "sclk_dpm_level_mhz_during_timed_region": sclk_mhz,
                "pmc": pmc}
         occ_txt = "occlusion heuristic + " if use_occ else ""
         result = {

@@ -89,6 +89,35 @@ def test_batched_fused_vertical_layout_full_size(eng, H, W, p, n_oracle, monkeyp
         assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D, subpixel=True), got[f]), f
 
 
+def test_cfg5_batch8_fused_wide_kernel_full_size(monkeypatch):
+    """configs[4] as bench.py's other_configs times it: 8 frames of 1536x2048, D = 256, the mask computed in the call.  The
+    default layout is the fused one with the 16-pixels-per-wave kernel (32-block groups, two per XCD): every frame equals
+    the 8-path layout bit for bit; one frame is also compared with the CPU oracle."""
+    import torch
+    from vppstereo_amd.engine import Engine
+    B, H, W, D = 8, 1536, 2048, 256
+    b = synth.make_batch(B, H, W, D, 0.01, seed=555)
+    eng = Engine()
+    args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(eng.device) for k in ("left", "right", "hints")]
+    occ = torch.empty((B, H, W), dtype=torch.uint8, device=eng.device)
+    out = eng.vpp_rsgm(*args, g_occ="occlusion_heuristic", occ_out=occ, seed=8, rsgm_kw=dict(dmax=D, subpixel=1))
+    eng.synchronize()
+    assert eng.uses_vert() == 3 and eng.fused_pixels_per_wave() == 16
+    monkeypatch.setenv("VPPX_VERT", "0")
+    eng8 = Engine()
+    out8 = eng8.vpp_rsgm(*args, g_occ="occlusion_heuristic", seed=8, rsgm_kw=dict(dmax=D, subpixel=1))
+    eng8.synchronize()
+    assert eng8.uses_vert() == 0
+    bad = (out != out8).flatten(1).any(1).nonzero().flatten().tolist()
+    assert not bad, bad
+    f = 5
+    conf = oracle.occlusion_heuristic(b["hints"][f])[1]
+    assert np.array_equal(conf, occ[f].cpu().numpy())
+    oracle.init_rand(8 + f)
+    lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], g_occ=conf)
+    assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D, subpixel=True), out[f].cpu().numpy())
+
+
 def test_cfg5_1536x2048_d256_full_size(eng):
     """configs[4]: 1536x2048, 1 % hints, D = 256 (0.8 G cells; ~40 s of oracle time)."""
     _fused_vs_oracle(eng, 1536, 2048, 256, 0.01, seed=105, with_occ=False)
