@@ -297,6 +297,79 @@ int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32
     return rsgm_launch_census_n(ctx, B, Hp, Wp, 1, &gray, &census);
 }
 
+// pad + gray + census of the fused pipeline in ONE launch (round 3): set 0 = the un-patterned left image, only its gray
+// image is needed (the P2 image, rsgm.py:270); sets 1, 2 = the patterned pair, only their census codes are: a block turns a
+// 64 x 16 tile (+ 2 pixels of halo) of the RGB image into gray values in LDS and takes the 24 comparisons from there, so the
+// patterned pair's gray images never go to HBM (2 x 17 MB per 32 frames written and read 25 times through the caches before).
+#define PGC_TX 64
+#define PGC_TY 16
+struct PgcArgs {
+    const u8 *img[3];
+    u8 *gray0;
+    u32 *census[2];
+    int B, H, W, C, Hp, Wp, pad_t, pad_l;
+};
+__global__ void __launch_bounds__(256) pad_gray_census_kernel(PgcArgs a)
+{
+    constexpr int LW = PGC_TX + 4, LH = PGC_TY + 4, LP = LW + 4; // tile with halo, row pitch
+    __shared__ u8 tile[LH * LP];
+    const int set = blockIdx.z / a.B, f = blockIdx.z % a.B;
+    const int x0 = blockIdx.x * PGC_TX, y0 = blockIdx.y * PGC_TY;
+    const u8 *img = set == 0 ? a.img[0] : (set == 1 ? a.img[1] : a.img[2]);
+    for (int i = threadIdx.x; i < LW * LH; i += 256) {
+        const int ly = i / LW, lx = i % LW;
+        int y = y0 + ly - 2, x = x0 + lx - 2;
+        y = min(max(y, 0), a.Hp - 1); // (outside the padded image only the census border reads, and that is zero anyway)
+        x = min(max(x, 0), a.Wp - 1);
+        const int sy = reflect_idx(y - a.pad_t, a.H), sx = reflect_idx(x - a.pad_l, a.W);
+        const u8 *s = img + (((size_t)f * a.H + sy) * a.W + sx) * a.C;
+        u32 v;
+        if (a.C == 3) v = (s[0] * 9798u + s[1] * 19235u + s[2] * 3735u + 16384u) >> 15;
+        else v = s[0];
+        tile[ly * LP + lx] = (u8)v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = x0 + tx;
+    if (x >= a.Wp) return;
+#pragma unroll
+    for (int r = 0; r < PGC_TY / 4; r++) {
+        const int ly = ty + 4 * r, y = y0 + ly;
+        if (y >= a.Hp) break;
+        const size_t o = ((size_t)f * a.Hp + y) * a.Wp + x;
+        const u8 *c = tile + (ly + 2) * LP + (tx + 2);
+        if (set == 0) {
+            a.gray0[o] = c[0];
+            continue;
+        }
+        u32 v = 0;
+        if (y >= 2 && y < a.Hp - 2 && x >= 2 && x < a.Wp - 2) {
+            const u32 cv = c[0];
+#pragma unroll
+            for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+                for (int dx = -2; dx <= 2; dx++) {
+                    if (dy == 0 && dx == 0) continue;
+                    v = (v << 1) | (u32)(c[dy * LP + dx] < cv);
+                }
+        }
+        (set == 1 ? a.census[0] : a.census[1])[o] = v;
+    }
+}
+
+int rsgm_launch_pad_gray_census(vppx_ctx *ctx, const RsgmGeom &g, const u8 *left, const u8 *left_vpp, const u8 *right_vpp, u8 *gray_left,
+                                u32 *census_l, u32 *census_r)
+{
+    PgcArgs a;
+    a.img[0] = left; a.img[1] = left_vpp; a.img[2] = right_vpp;
+    a.gray0 = gray_left; a.census[0] = census_l; a.census[1] = census_r;
+    a.B = g.B; a.H = g.H; a.W = g.W; a.C = g.C; a.Hp = g.Hp; a.Wp = g.Wp; a.pad_t = g.pad_t; a.pad_l = g.pad_l;
+    dim3 grid((g.Wp + PGC_TX - 1) / PGC_TX, (g.Hp + PGC_TY - 1) / PGC_TY, 3 * g.B);
+    pad_gray_census_kernel<<<grid, 256, 0, ctx->stream>>>(a);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // materialised Hamming cost volume (call site rsgm.py:44) -- stage API only; the fused
 // path recomputes costs from the census pair inside the aggregation kernel.

@@ -668,25 +668,17 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     int rc;
     const size_t npp = (size_t)g.B * g.Hp * g.Wp;
     const size_t ncell = npp * g.D;
-    u8 *gl, *glv, *grv;
+    u8 *gl;
     u32 *cl, *cr_raw;
     if ((rc = ws_get(ctx, WS_GRAY_L, npp, &gl))) return rc;
-    if ((rc = ws_get(ctx, WS_GRAY_LV, npp, &glv))) return rc;
-    if ((rc = ws_get(ctx, WS_GRAY_RV, npp, &grv))) return rc;
     if ((rc = ws_get(ctx, WS_CENSUS_L, npp, &cl))) return rc;
     if ((rc = ws_get(ctx, WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
     u32 *cr = cr_raw + 512;
     ctx->last_gl = gl; ctx->last_cl = cl; ctx->last_cr = cr;
-    {
-        const u8 *imgs[3] = {left, left_vpp, right_vpp};
-        u8 *grays[3] = {gl, glv, grv};
-        if ((rc = rsgm_launch_pad_gray_n(ctx, g, 3, imgs, grays))) return rc;
-        stage_mark(ctx, ST_PAD_GRAY);
-        const u8 *gsrc[2] = {glv, grv};
-        u32 *cdst[2] = {cl, cr};
-        if ((rc = rsgm_launch_census_n(ctx, g.B, g.Hp, g.Wp, 2, gsrc, cdst))) return rc;
-        stage_mark(ctx, ST_CENSUS);
-    }
+    // pad + gray of the three images and the census of the patterned pair: one launch, the pair's gray images stay in LDS
+    if ((rc = rsgm_launch_pad_gray_census(ctx, g, left, left_vpp, right_vpp, gl, cl, cr))) return rc;
+    stage_mark(ctx, ST_PAD_GRAY);
+    stage_mark(ctx, ST_CENSUS);
     if ((rc = front_end(ctx))) return rc; // pipelined call: the front stage ends here
 
     u16 *lut_d;

@@ -241,6 +241,8 @@ int rsgm_launch_pad_gray(vppx_ctx *ctx, const RsgmGeom &g, const u8 *img, u8 *gr
 int rsgm_launch_pad_gray_n(vppx_ctx *ctx, const RsgmGeom &g, int n, const u8 *const *img, u8 *const *gray); // n <= 3, one launch
 int rsgm_launch_to_nchw(vppx_ctx *ctx, int B, int H, int W, int C, int mult, const u8 *src, void *dst, int bf16);
 int rsgm_launch_census(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, u32 *census);
+int rsgm_launch_pad_gray_census(vppx_ctx *ctx, const RsgmGeom &g, const u8 *left, const u8 *left_vpp, const u8 *right_vpp, u8 *gray_left,
+                                u32 *census_l, u32 *census_r); // the three of the fused pipeline in one launch
 int rsgm_launch_census_n(vppx_ctx *ctx, int B, int Hp, int Wp, int n, const u8 *const *gray, u32 *const *census); // n <= 2
 int rsgm_launch_cost(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u32 *cl, const u32 *cr, u16 *dsi);
 int rsgm_launch_guided_dsi(vppx_ctx *ctx, const RsgmGeom &g, u16 *dsi, const float *hints, const float *valid);
