@@ -1363,6 +1363,7 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
     __syncthreads();
     const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
     const int group = (jb / a.nbg) * 8 + xcd, bi = jb % a.nbg;
+    if (group >= 2 * a.B) return; // the grid is rounded up to whole rounds of 8 groups (one per XCD)
     const int f = group >> 1, pass = group & 1;
     const int wv = bi * 4 + (int)(threadIdx.x >> 6);
     if (wv >= a.nwv) return;
@@ -1637,6 +1638,7 @@ __global__ void __launch_bounds__(256, 2) sgm_vert4_kernel(Vert3Args a)
     __syncthreads();
     const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
     const int group = (jb / a.nbg) * 8 + xcd, bi = jb % a.nbg;
+    if (group >= 2 * a.B) return; // the grid is rounded up to whole rounds of 8 groups (one per XCD)
     const int f = group >> 1, pass = group & 1;
     const int wv = bi * 4 + (int)(threadIdx.x >> 6);
     if (wv >= a.nwv) return;
@@ -1905,7 +1907,7 @@ bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2)
     // shape conditions only (rsgm_vert3_fits has the residency condition): edge values and their packed minimum must
     // stay below 1024 (tag bits), the three-path sum below 256; record offsets are 32-bit byte offsets into one buffer
     // (kept below 1 GiB)
-    return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255 && (2 * B) % 8 == 0 && Wp % 8 == 0 && Hp < 4095 &&
+    return (D == 64 || D == 128 || D == 192 || D == 256) && 3 * (24 + maxp2) <= 255 && B > 0 && Wp % 8 == 0 && Hp < 4095 &&
            (size_t)2 * B * (Wp / 8) * (V3_RING * 2 * 8 * 32) * sizeof(u32) < ((size_t)1 << 30);
 }
 
@@ -1924,7 +1926,7 @@ static bool v3_wide(const vppx_ctx *ctx, int B, int Wp, int D)
     if (ctx->v3.ppw == 16) return true;
     const int nbg = (Wp / 16 + 3) / 4;
     const int resident = ctx->v3.cus_per_xcd * ctx->v3.blocks_per_cu16[v3_dk(D)] / (nbg > 0 ? nbg : 1); // whole groups per XCD
-    return resident > 0 && 2 * B / 8 >= resident;
+    return resident > 0 && (2 * B + 7) / 8 >= resident;
 }
 
 bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D) { return v3_wide(ctx, B, Wp, D); }
@@ -1970,7 +1972,7 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     a.serial = ++ctx->v3.serial;
     if (a.serial == 0) a.serial = ++ctx->v3.serial;
     VPPX_HIP(hipMemsetAsync(xbuf, 0, rsgm_vert3_xbuf_bytes(B, Wp, D), stream)); // no record of an earlier launch may match
-    const dim3 grid((unsigned)(2 * B * a.nbg));
+    const dim3 grid((unsigned)((2 * B + 7) / 8 * 8 * a.nbg)); // whole rounds of 8 groups; groups >= 2B exit at once
     if (wide && D == 64) sgm_vert4_kernel<16><<<grid, 256, 0, stream>>>(a);
     else if (wide && D == 128) sgm_vert4_kernel<32><<<grid, 256, 0, stream>>>(a);
     else if (wide && D == 192) sgm_vert4_kernel<48><<<grid, 256, 0, stream>>>(a);
