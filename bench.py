@@ -659,8 +659,13 @@ def run_rank(args):
             result["cpu_baseline"] = None
         if world == 1 and not args.no_other_configs and not args.shape and not args.uniform_random and not args.graph:
             # the other BASELINE.json configurations on this one GPU (their multi-GPU form shards frames: section 7 of DESIGN.md)
+            q3 = eng.batch_quantum(375, 1242, 192)
+            cfg3_b = 3 * q3 if 0 < q3 <= 16 else 32
+            result["config"]["batch_quantum"] = {"540x960x192": eng.batch_quantum(H, W, D), "375x1242x192": q3, "1536x2048x256": eng.batch_quantum(1536, 2048, 256)}
             result["other_configs"] = [
-                other_config(eng, torch, synth, "cfg3: KITTI-sized 375x1242 stream, 5% hints, D=192, 32 frames per step", 375, 1242, 192, 0.05, 32),
+                # frames per step = three batch quanta of this width (vppx_batch_quantum: 12 on an MI355X -> 36 frames; the
+                # 32 of rounds 1-2 left the third round of the lock-step kernel two-thirds full)
+                other_config(eng, torch, synth, "cfg3: KITTI-sized 375x1242 stream, 5%% hints, D=192, %d frames per step" % cfg3_b, 375, 1242, 192, 0.05, cfg3_b),
                 other_config(eng, torch, synth, "cfg5: 1536x2048 indoor pairs, 1% hints, D=256, 8 frames per step", 1536, 2048, 256, 0.01, 8, steps=3, warmup=1),
                 {"config": "cfg2 literal: one 540x960 pair per call, D=192", "ms_per_frame": round(b1_ms, 4),
                  "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),

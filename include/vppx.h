@@ -329,6 +329,12 @@ int vppx_uses_vert(vppx_ctx *ctx);
  * batch fills the chip with its groups), 8 = sgm_vert3_kernel (8 lanes per pixel; VPPX_V3_PPW = 8 / 16 forces one),
  * 0 = the last call did not use the fused layout. */
 int vppx_fused_pixels_per_wave(vppx_ctx *ctx);
+/* Batch quantum of the fused layout for H x W frames and this disparity range: the number of frames that fills the GPU
+ * with one whole round of (frame, pass) groups of the lock-step kernel -- batches that are a multiple of it leave no
+ * part-filled last round (540 x 960 x 192 on an MI355X: 16; 375 x 1242 x 192: 12).  0 when the fused layout does not apply
+ * to this device or shape.  A scheduling hint only: every batch size gives the same results.  (Runs a one-time device
+ * probe on first use; not inside a graph capture.) */
+int vppx_batch_quantum(vppx_ctx *ctx, int H, int W, int dmax);
 /* Per-stage hipEvent timing of the last vppx_vpp_rsgm_dev/vppx_rsgm_dev call when stage
  * timing is enabled: fills ms[0..n) and returns the number of stages; names via
  * vppx_stage_name(i). */

@@ -333,3 +333,25 @@ def test_fused_kernels_soak_alone_and_next_to_competing_work():
         torch.cuda.synchronize()
         eng.status()
         assert eng.uses_vert() == 3
+
+
+def test_batch_quantum_is_a_whole_round_of_the_lock_step_kernel():
+    """vppx_batch_quantum: frames per full round of (frame, pass) groups of the 16-pixels-per-wave kernel.  A hint, not a
+    constraint: batches of one quantum, and of a quantum + 1 (a part-filled round, a ghost round of groups), both take the
+    fused layout and give the 8-path layout's bits."""
+    import torch
+    eng = _engine()
+    q = eng.batch_quantum(60, 480, 192)
+    assert q > 0 and q % 4 == 0          # whole groups per XCD x 8 XCDs / 2 passes
+    assert eng.batch_quantum(540, 960, 192) > 0 and eng.batch_quantum(375, 1242, 192) > 0
+    assert eng.batch_quantum(375, 1242, 192) <= eng.batch_quantum(540, 960, 192)   # wider frames: fewer groups resident
+    assert eng.batch_quantum(60, 480, 100) == 0                                   # no fused layout for this range
+    ref_eng = _engine(VPPX_VERT=0)
+    for B in (8, 9):
+        b, args = _small_batch(eng, B=B, H=60, W=480, seed=70 + B)
+        out = eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=192))
+        eng.synchronize()
+        assert eng.uses_vert() == 3
+        ref = ref_eng.vpp_rsgm(*[a.to(ref_eng.device) for a in args], seed=3, rsgm_kw=dict(dmax=192))
+        ref_eng.synchronize()
+        assert torch.equal(out, ref), B

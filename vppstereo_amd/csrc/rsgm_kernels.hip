@@ -1931,6 +1931,16 @@ static bool v3_wide(const vppx_ctx *ctx, int B, int Wp, int D)
 
 bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D) { return v3_wide(ctx, B, Wp, D); }
 
+// Frames per full round of the 16-pixels-per-wave kernel at this width: (whole groups resident per XCD) x 8 XCDs / 2 passes.
+// A batch that is a multiple of it leaves no part-filled last round (0: the fused layout does not apply).
+int rsgm_vert3_frames_per_round(const vppx_ctx *ctx, int Wp, int D)
+{
+    if (!ctx->v3.ok || Wp % 16 != 0 || !(D == 64 || D == 128 || D == 192 || D == 256)) return 0;
+    const int nbg = (Wp / 16 + 3) / 4;
+    const int resident = ctx->v3.cus_per_xcd * ctx->v3.blocks_per_cu16[v3_dk(D)] / nbg;
+    return resident * ctx->v3.nxcd / 2;
+}
+
 bool rsgm_vert3_fits(const vppx_ctx *ctx, int B, int Wp, int D)
 {
     if (!ctx->v3.ok) return false;

@@ -319,6 +319,18 @@ extern "C" int vppx_status(vppx_ctx *ctx)
 extern "C" long vppx_lockstep_failures(vppx_ctx *ctx) { return ctx ? ctx->lockstep_failures : 0; }
 extern "C" int vppx_fused_pixels_per_wave(vppx_ctx *ctx) { return (ctx && ctx->last_vert == 3) ? ctx->v3.last_ppw : 0; }
 
+static void make_geom(int B, int H, int W, int C, int D, RsgmGeom &g);
+static int v3_probe_once(vppx_ctx *ctx);
+extern "C" int vppx_batch_quantum(vppx_ctx *ctx, int H, int W, int dmax)
+{
+    if (!ctx || H < 1 || W < 1 || ctx->capturing) return 0;
+    DevGuard dev_guard_(ctx->device);
+    if (ctx->vert3_broken || v3_probe_once(ctx) != 0 || ctx->vert3_broken) return 0;
+    RsgmGeom g;
+    make_geom(1, H, W, 3, dmax, g);
+    return rsgm_vert3_frames_per_round(ctx, g.Wp, g.D);
+}
+
 extern "C" size_t vppx_workspace_bytes(const vppx_ctx *ctx)
 {
     if (!ctx) return 0;
@@ -393,6 +405,20 @@ static int upload(vppx_ctx *ctx, WsSlot s, const void *host, size_t bytes, void 
 static int download(vppx_ctx *ctx, void *host, const void *dev, size_t bytes)
 {
     VPPX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+// first fused launch of a context (or the first question about it): block placement and residency of this device
+static int v3_probe_once(vppx_ctx *ctx)
+{
+    if (ctx->vert3_probed) return 0;
+    int rc;
+    u32 *probe;
+    bool ok = false;
+    if ((rc = ws_get(ctx, WS_VMIN, (size_t)512, (u16 **)&probe))) return rc;
+    if ((rc = rsgm_vert3_probe(ctx, probe, &ok))) return rc;
+    ctx->vert3_probed = true;
+    if (!ok) ctx->vert3_broken = true;
     return 0;
 }
 
@@ -481,12 +507,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
         // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes
         // (8 XCDs, round-robin), and how many blocks of this build of the kernel does one XCD hold?
-        u32 *probe;
-        bool ok = false;
-        if ((rc = ws_get(ctx, WS_VMIN, (size_t)512, (u16 **)&probe))) return rc;
-        if ((rc = rsgm_vert3_probe(ctx, probe, &ok))) return rc;
-        ctx->vert3_probed = true;
-        if (!ok) ctx->vert3_broken = true;
+        if ((rc = v3_probe_once(ctx))) return rc;
     }
     if (!ctx->vert3_probed) v3_ok = false; // (e.g. a first call inside a graph capture takes the 8-path layout)
     v3_ok = v3_ok && !ctx->vert3_broken && rsgm_vert3_fits(ctx, g.B, g.Wp, g.D); // a whole group + early arrivals resident per XCD

@@ -254,6 +254,7 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
 int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev, bool *ok);
 bool rsgm_vert3_supported(int B, int Hp, int Wp, int D, int maxp2);
 bool rsgm_vert3_fits(const vppx_ctx *ctx, int B, int Wp, int D);
+int rsgm_vert3_frames_per_round(const vppx_ctx *ctx, int Wp, int D);
 bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,

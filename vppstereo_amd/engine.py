@@ -316,6 +316,11 @@ class Engine:
         """16 / 8: which fused vertical kernel the last call used (sgm_vert4_kernel / sgm_vert3_kernel); 0: none."""
         return int(self.lib.vppx_fused_pixels_per_wave(self.ctx.handle))
 
+    def batch_quantum(self, h, w, dmax=192):
+        """Frames per full round of the fused layout's lock-step kernel for h x w frames (a scheduling hint: batches that are
+        a multiple of it leave no part-filled last round; 0 when the fused layout does not apply)."""
+        return int(self.lib.vppx_batch_quantum(self.ctx.handle, int(h), int(w), int(dmax)))
+
     def enable_stage_timing(self, on=True):
         _lib.check(self.lib.vppx_enable_stage_timing(self.ctx.handle, int(bool(on))))
 
