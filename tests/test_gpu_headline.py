@@ -355,3 +355,35 @@ def test_batch_quantum_is_a_whole_round_of_the_lock_step_kernel():
         ref = ref_eng.vpp_rsgm(*[a.to(ref_eng.device) for a in args], seed=3, rsgm_kw=dict(dmax=192))
         ref_eng.synchronize()
         assert torch.equal(out, ref), B
+
+
+def test_pipelined_stream_of_small_batches_starts_the_next_front_stage_early():
+    """Fewer than 8 frames per call: the next call's front stage starts next to THIS call's aggregation (two alternating
+    sets of gray / census images).  A stream that mixes single frames, small and large batches, with no synchronisation
+    in between, must give the unpipelined results call by call."""
+    import torch
+    ref_eng, eng = _engine(), _engine()
+    eng.set_pipeline(True)
+    dev = eng.device
+    shapes = [(1, 60, 200), (1, 60, 200), (2, 45, 130), (8, 40, 120), (1, 60, 200), (3, 33, 90), (12, 40, 120), (1, 45, 130), (1, 60, 200)]
+    batches, outs, occs, refs = [], [], [], []
+    for i, (B, H, W) in enumerate(shapes):
+        b = synth.make_batch(B, H, W, 192, 0.05, seed=300 + i)
+        batches.append([_dev(eng, b[k]) for k in ("left", "right", "hints")])
+        outs.append([torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(3)])
+        occs.append(torch.empty((B, H, W), dtype=torch.uint8, device=dev))
+    for i, (l, r, h) in enumerate(batches):
+        refs.append(ref_eng.vpp_rsgm(l, r, h, g_occ="occlusion_heuristic", seed=i, rsgm_kw=dict(dmax=192)).clone())
+    ref_eng.synchronize()
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    ev.record()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, (l, r, h) in enumerate(batches):
+            eng.vpp_rsgm(l, r, h, g_occ="occlusion_heuristic", occ_out=occs[i], out=outs[i][rep], seed=i, rsgm_kw=dict(dmax=192),
+                         inputs_ready=ev)
+    eng.synchronize()
+    for rep in range(3):
+        for i in range(len(batches)):
+            assert torch.equal(outs[i][rep], refs[i]), (rep, i, shapes[i])

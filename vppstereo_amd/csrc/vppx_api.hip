@@ -668,6 +668,15 @@ static int front_end(vppx_ctx *ctx)
     for (int i = 0; i < ctx->n_pipe_copy; i++)
         VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_pipe_copy = 0;
+    if (ctx->pipe_call && ctx->pipe_early) {
+        // Few frames per call: the aggregation is a handful of long dependent chains that leave most of the GPU idle, so
+        // the NEXT call's front stage may start right now, next to it.  From here on nothing of this call reads what a front
+        // stage writes except the gray / census images its aggregation takes, and those alternate between two sets by call
+        // parity; the set this call uses is rewritten by the front stage of call k+2, which waits for THIS event of call
+        // k+1 -- recorded on the in-order launch stream behind call k's aggregation.
+        VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
+        ctx->have_agg_done = true;
+    }
     return 0;
 }
 struct FrontGuard { // error paths: never leave the context on the front stream
@@ -691,9 +700,14 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const size_t ncell = npp * g.D;
     u8 *gl;
     u32 *cl, *cr_raw;
-    if ((rc = ws_get(ctx, WS_GRAY_L, npp, &gl))) return rc;
-    if ((rc = ws_get(ctx, WS_CENSUS_L, npp, &cl))) return rc;
-    if ((rc = ws_get(ctx, WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
+    // pipelined calls alternate between two sets of the images the aggregation reads (see front_end); with fewer than 8
+    // frames per call (8-path layout, a GPU mostly idle during the aggregation) the next front stage starts early
+    const bool alt = ctx->pipe_call && (ctx->pipe_parity & 1);
+    if (ctx->pipe_call) ctx->pipe_parity ^= 1;
+    ctx->pipe_early = ctx->pipe_call && g.B < 8;
+    if ((rc = ws_get(ctx, alt ? WS_GRAY_L2 : WS_GRAY_L, npp, &gl))) return rc;
+    if ((rc = ws_get(ctx, alt ? WS_CENSUS_L2 : WS_CENSUS_L, npp, &cl))) return rc;
+    if ((rc = ws_get(ctx, alt ? WS_CENSUS_R2 : WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
     u32 *cr = cr_raw + 512;
     ctx->last_gl = gl; ctx->last_cl = cl; ctx->last_cr = cr;
     // pad + gray of the three images and the census of the patterned pair: one launch, the pair's gray images stay in LDS
@@ -716,7 +730,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     const void *vols[8];
     int nvol = 0, elem_bytes = 1;
     if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0, hints, validhints))) return rc;
-    if (ctx->pipe_call) { // the next pipelined call's front stage may start now
+    if (ctx->pipe_call && !ctx->pipe_early) { // the next pipelined call's front stage may start now
         VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
         ctx->have_agg_done = true;
     }

@@ -64,6 +64,9 @@ enum WsSlot {
     WS_GRAY_RV,
     WS_CENSUS_L,
     WS_CENSUS_R,
+    WS_GRAY_L2,      // second set of the images the aggregation reads (pipelined calls alternate: front_end)
+    WS_CENSUS_L2,
+    WS_CENSUS_R2,
     WS_PATHS,        // 8 per-path L volumes
     WS_S,            // aggregated volume (u16)
     WS_SV,           // per-pass sums of the vertical/diagonal paths (band-marching kernel)
@@ -124,6 +127,8 @@ struct vppx_ctx {
     bool front_active = false;     // ctx->stream currently is stream_front
     bool pipe_call = false;        // the running vpp_rsgm call is pipelined (record ev_agg_done after its aggregation)
     bool have_agg_done = false;
+    bool pipe_early = false;       // this pipelined call lets the next front stage start next to its aggregation (few frames per call)
+    int pipe_parity = 0;           // which set of gray / census images the next pipelined call writes
     const u8 *last_gl = nullptr;   // the images the last call aggregated from (timing helpers)
     const u32 *last_cl = nullptr, *last_cr = nullptr;
     hipStream_t stream_front = nullptr, main_saved = nullptr;
