@@ -223,6 +223,14 @@ int vppx_subpixel_refine(vppx_ctx *ctx, const uint16_t *dsi, float *disp, int w,
 int vppx_median3x3(vppx_ctx *ctx, const float *src, float *dst, int w, int h);
 
 /* ---- rSGM: whole compute_rsgm (rsgm.py:250-294), batched -------------------------------- */
+/* Stage API: the post-processing of compute_rsgm (models/rsgm/rsgm.py:275-292) on device buffers: crop of the padded
+ * left / right disparity maps [B][Hp][Wp] (Hp, Wp = H, W rounded up to multiples of 16, the frame centred as rsgm.py:254-260
+ * pads it), left/right check (:230-248, threshold 1), astype(uint8), cv2.filterSpeckles(0, 200, 10), astype(float32),
+ * sub-pixel values restored where the integer map kept a pixel (subpixel != 0), _interpolate_background (:185-227).
+ * disp_out: [B][H][W] float32. */
+int vppx_rsgm_post_dev(vppx_ctx *ctx, int B, int H, int W, const float *disp_l_pad, const float *disp_r_pad, int subpixel,
+                       float *disp_out);
+
 /* left / left_vpp / right_vpp: uint8 [B,H,W,C] (C = 1 or 3); disp_out: float32 [B,H,W].
  * hints / validhints: float32 [B,H,W] or both NULL; non-NULL = --guided (_guided_dsi, rsgm.py:116-127). */
 int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,

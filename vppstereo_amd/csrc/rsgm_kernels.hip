@@ -3007,40 +3007,8 @@ int rsgm_launch_median_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const f
 //   crop -> left/right check (:230-248) -> zero mask==128 -> astype(uint8) -> filterSpeckles
 //   (0,200,10) -> astype(float32) -> restore sub-pixel -> _interpolate_background (:185-227)
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) crop_lrc_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
-                                                       float *__restrict__ fdc, u8 *__restrict__ fd8, int H, int W, int Hp,
-                                                       int Wp, int pad_t, int pad_l)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, f = blockIdx.z;
-    if (x >= W) return;
-    const float *rl = dl + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
-    const float *rr = dr + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
-    const float v = rl[x];
-    float keep = v;
-    if (v > 0) {
-        const int d = (int)rintf(v); // round half to even (numba round)
-        const int xd = x - d;
-        if (0 <= xd && xd <= W - 1) {
-            const float rv = rr[xd];
-            if (rv > 0 && fabsf(__fsub_rn(v, rv)) > 1.0f) keep = 0; // mask 128
-        } else {
-            keep = 0; // mask 128
-        }
-    }
-    const size_t o = ((size_t)f * H + y) * W + x;
-    fdc[o] = v;
-    fd8[o] = (u8)keep; // astype(np.uint8): truncation, values in [0,256)
-}
-
-// Connected components for cv2.filterSpeckles (4-connectivity, |a-b| <= maxDiff, pixels equal
-// to newVal excluded), run-based union-find:
-//   runs   : every pixel gets the index of the first pixel of its horizontal run (segmented
-//            max-scan per row); the run's last pixel stores the run length at the run start
-//   vunion : one union per place where a vertical link begins (not one per pixel)
-//   count  : one atomicAdd(run length) per run on the component root (a giant component would
-//            otherwise serialise half a million atomics on one address)
-//   apply  : components with <= maxSpeckleSize pixels are set to newVal
+// Connected components for cv2.filterSpeckles (4-connectivity, |a-b| <= maxDiff, pixels equal to newVal excluded):
+// tile-local labelling in LDS, union-find in global memory only across tile borders (kernels below).
 __device__ __forceinline__ int uf_find(int *label, int i)
 {
     int p = label[i];
@@ -3083,107 +3051,205 @@ __device__ __forceinline__ bool px_link(int a, int b, int new_val, int max_diff)
     return a != new_val && b != new_val && abs(a - b) <= max_diff;
 }
 
-__global__ void __launch_bounds__(256) speckle_runs_kernel(const u8 *__restrict__ img, int *__restrict__ label,
-                                                           int *__restrict__ runlen, int H, int W, int new_val, int max_diff)
+// speckle_tile_kernel: crop + left/right check + the connected components INSIDE a 64 x 32 tile, in LDS (a wave owns whole
+// tile rows: horizontal runs by one segmented max-scan per row, vertical links by union-find on the run starts with LDS
+// atomics, component sizes by one LDS add per run).  Every pixel gets the frame index of its tile-local root, the root
+// pixel the local component's size (0 everywhere else).
+// speckle_border_kernel: unions across tile borders only (a few thousand links per frame instead of one per vertical run
+// contact); speckle_total_kernel: every local root adds its size to its global root; speckle_apply_kernel: components of at most
+// maxSpeckleSize pixels become newVal, float32 again, sub-pixel values restored (rsgm.py:285-290).
+// (Rounds 1-2 labelled whole frames in global memory -- row runs, one union per vertical run contact, a size per run: 7 launches,
+// 0.52 ms per 32 frames and 0.10 ms for one frame, against 4 launches, 0.25 / 0.04 ms.)
+#define SPK_TW 64
+#define SPK_TH 32
+__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_find(const int *lab, int i)
 {
-    __shared__ int s_w[4];
-    __shared__ int s_carry;
-    const int y = blockIdx.x, f = blockIdx.y;
-    const size_t base = ((size_t)f * H + y) * W;
+    int p = lds_ld(&lab[i]);
+    while (p != i) {
+        i = p;
+        p = lds_ld(&lab[i]);
+    }
+    return i;
+}
+__device__ __forceinline__ void lds_union(int *lab, int a, int b)
+{
+    while (true) {
+        a = lds_find(lab, a);
+        b = lds_find(lab, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; } // a > b: hang a under b (labels only ever decrease)
+        const int old = atomicMin(&lab[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void __launch_bounds__(256) speckle_tile_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
+                                                           float *__restrict__ fdc, u8 *__restrict__ fd8, int *__restrict__ label,
+                                                           int *__restrict__ size, int H, int W, int Hp, int Wp, int pad_t, int pad_l,
+                                                           int new_val, int max_diff)
+{
+    __shared__ int s_lab[SPK_TH * SPK_TW];
+    __shared__ int s_cnt[SPK_TH * SPK_TW];
+    __shared__ u8 s_val[SPK_TH * SPK_TW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = -1;
-    __syncthreads();
-    for (int x0 = 0; x0 < W; x0 += 256) {
-        const int x = x0 + threadIdx.x;
-        int v = new_val, vprev = new_val, vnext = new_val;
-        if (x < W) {
-            v = img[base + x];
-            if (x > 0) vprev = img[base + x - 1];
-            if (x + 1 < W) vnext = img[base + x + 1];
+    const int tx0 = blockIdx.x * SPK_TW, ty0 = blockIdx.y * SPK_TH, f = blockIdx.z;
+    const int x = tx0 + lane;
+    constexpr int RPW = SPK_TH / 4; // tile rows per wave
+    int vv[RPW], ss[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wv * RPW + k, y = ty0 + r;
+        int v = new_val;
+        if (x < W && y < H) {
+            // crop + left/right check (rsgm.py:230-248, 275-283)
+            const float *rl = dl + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
+            const float *rr = dr + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
+            const float dv = rl[x];
+            float keep = dv;
+            if (dv > 0) {
+                const int d = (int)rintf(dv); // round half to even (numba round)
+                const int xd = x - d;
+                if (0 <= xd && xd <= W - 1) {
+                    const float rv = rr[xd];
+                    if (rv > 0 && fabsf(__fsub_rn(dv, rv)) > 1.0f) keep = 0; // mask 128
+                } else {
+                    keep = 0; // mask 128
+                }
+            }
+            const size_t o = ((size_t)f * H + y) * W + x;
+            fdc[o] = dv;
+            const u8 k8 = (u8)keep; // astype(np.uint8): truncation, values in [0,256)
+            fd8[o] = k8;
+            v = k8;
         }
-        const bool inside = x < W && v != new_val;
-        const bool start = inside && !(x > 0 && px_link(vprev, v, new_val, max_diff));
-        int s = start ? x : -1; // inclusive max-scan of run starts
+        const int vprev = __shfl_up(v, 1);
+        const bool in = v != new_val;
+        const bool start = in && !(lane > 0 && px_link(vprev, v, new_val, max_diff));
+        int s = start ? lane : -1; // inclusive max-scan of run starts over the tile row
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(s, off);
             if (lane >= off) s = max(s, t);
         }
-        if (lane == 63) s_w[wv] = s;
-        __syncthreads();
-        int pre = s_carry;
-        for (int w = 0; w < wv; w++) pre = max(pre, s_w[w]);
-        s = max(s, pre);
-        if (inside) {
-            label[base + x] = y * W + s;
-            const bool end = !(x + 1 < W && px_link(v, vnext, new_val, max_diff));
-            if (end) runlen[base + s] = x - s + 1;
-        } else if (x < W) {
-            label[base + x] = -1;
+        vv[k] = v;
+        ss[k] = s;
+        const int p = r * SPK_TW + lane;
+        s_val[p] = (u8)v;
+        s_lab[p] = in ? r * SPK_TW + s : p;
+        s_cnt[p] = 0;
+    }
+    __syncthreads();
+    // vertical links: one union per place where a link between two runs begins
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wv * RPW + k, p = r * SPK_TW + lane;
+        if (r == 0) continue;
+        const int a = s_val[p - SPK_TW], b = vv[k];
+        if (!px_link(a, b, new_val, max_diff)) continue;
+        if (lane > 0) {
+            const int a0 = s_val[p - SPK_TW - 1], b0 = s_val[p - 1];
+            if (px_link(a0, b0, new_val, max_diff) && px_link(a0, a, new_val, max_diff) && px_link(b0, b, new_val, max_diff)) continue;
         }
-        __syncthreads();
-        if (threadIdx.x == 255) s_carry = s;
-        __syncthreads();
+        lds_union(s_lab, lds_ld(&s_lab[p - SPK_TW]), r * SPK_TW + ss[k]);
+    }
+    __syncthreads();
+    // sizes: the last pixel of a run adds the run's length to the root
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wv * RPW + k, p = r * SPK_TW + lane;
+        const int v = vv[k];
+        if (v == new_val) continue;
+        const int vnext = lane < 63 ? (int)s_val[p + 1] : new_val;
+        if (lane < 63 && px_link(v, vnext, new_val, max_diff)) continue;
+        atomicAdd(&s_cnt[lds_find(s_lab, r * SPK_TW + ss[k])], lane - ss[k] + 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wv * RPW + k, y = ty0 + r, p = r * SPK_TW + lane;
+        if (x >= W || y >= H) continue;
+        const int v = vv[k];
+        const int root = v != new_val ? lds_find(s_lab, r * SPK_TW + ss[k]) : p;
+        const size_t o = ((size_t)f * H + y) * W + x;
+        label[o] = (ty0 + root / SPK_TW) * W + tx0 + root % SPK_TW;
+        size[o] = (v != new_val && root == p) ? s_cnt[p] : 0;
     }
 }
 
-__global__ void __launch_bounds__(256) speckle_vunion_kernel(const u8 *__restrict__ img, int *__restrict__ label, int H, int W,
+__global__ void __launch_bounds__(256) speckle_border_kernel(const u8 *__restrict__ img, int *__restrict__ label, int H, int W,
                                                              int new_val, int max_diff)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, f = blockIdx.z;
-    if (x >= W || y + 1 >= H) return;
+    const int f = blockIdx.y;
     const u8 *im = img + (size_t)f * H * W;
     int *lb = label + (size_t)f * H * W;
-    const int i = y * W + x;
-    const int a = im[i], b = im[i + W];
+    const int nby = (H - 1) / SPK_TH, nbx = (W - 1) / SPK_TW; // tile borders with pixels on both sides
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    int ia, ib, ja = -1, jb = -1; // the pair, and the pair before it along the border (same two tiles only)
+    if (idx < nby * W) {
+        const int x = idx % W, y = SPK_TH * (idx / W + 1) - 1;
+        ia = y * W + x;
+        ib = ia + W;
+        if (x % SPK_TW != 0) { ja = ia - 1; jb = ib - 1; }
+    } else {
+        idx -= nby * W;
+        if (idx >= nbx * H) return;
+        const int y = idx % H, x = SPK_TW * (idx / H + 1) - 1;
+        ia = y * W + x;
+        ib = ia + 1;
+        if (y % SPK_TH != 0) { ja = ia - W; jb = ib - W; }
+    }
+    const int a = im[ia], b = im[ib];
     if (!px_link(a, b, new_val, max_diff)) return;
-    // skip when the pixel to the left carries the same vertical link between the same two runs
-    if (x > 0) {
-        const int a0 = im[i - 1], b0 = im[i + W - 1];
+    if (ja >= 0) { // the pair before links the same two tile-local components: skip (never across a tile corner: the links
+                   // this argument leans on must be ones the tile kernel has already made)
+        const int a0 = im[ja], b0 = im[jb];
         if (px_link(a0, b0, new_val, max_diff) && px_link(a0, a, new_val, max_diff) && px_link(b0, b, new_val, max_diff)) return;
     }
-    uf_union(lb, lb[i], lb[i + W]);
+    uf_union(lb, lb[ia], lb[ib]);
 }
 
-__global__ void __launch_bounds__(256) speckle_count_kernel(int *__restrict__ label, const int *__restrict__ runlen,
-                                                            int *__restrict__ count, int H, int W)
+// every tile-local root adds its component's size to its global root (all unions are done: roots are final)
+__global__ void __launch_bounds__(256) speckle_total_kernel(int *__restrict__ label, int *__restrict__ size, size_t npix_frame, int nframes)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, f = blockIdx.z;
-    if (x >= W) return;
-    const size_t base = (size_t)f * H * W;
-    const int i = y * W + x;
-    // run starts are the only pixels with a run length (runlen is zeroed before every call)
-    if (runlen[base + i] <= 0) return;
-    // all unions are done: walk to the root with path halving (shortcuts to an ancestor are benign
-    // under concurrency) and leave the run start pointing at the root for the apply pass
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_frame * nframes) return;
+    const int sz = size[i];
+    if (sz <= 0) return;
+    const size_t base = i / npix_frame * npix_frame;
     int *lb = label + base;
-    int c = i, p = lb[c];
-    while (p != c) {
+    const int me = (int)(i - base);
+    int c = me, p = lb[c];
+    while (p != c) { // path halving (shortcuts to an ancestor are benign under concurrency)
         const int gp = lb[p];
         if (gp != p) lb[c] = gp;
         c = gp;
         p = lb[c];
     }
-    if (c != i) lb[i] = c;
-    atomicAdd(&count[base + c], runlen[base + i]);
+    if (c != me) {
+        lb[me] = c;
+        atomicAdd(&size[base + c], sz);
+    }
 }
 
-__global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict__ fd8, int *__restrict__ label,
-                                                            const int *__restrict__ count, const float *__restrict__ fdc,
-                                                            float *__restrict__ out, int H, int W, int new_val, int max_size,
-                                                            int subpixel)
+__global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict__ fd8, const int *__restrict__ label,
+                                                             const int *__restrict__ size, const float *__restrict__ fdc,
+                                                             float *__restrict__ out, size_t npix_frame, int nframes, int new_val,
+                                                             int max_size, int subpixel)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, f = blockIdx.z;
-    if (x >= W) return;
-    const size_t o = ((size_t)f * H + y) * W + x;
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= npix_frame * nframes) return;
     int v = fd8[o];
     if (v != new_val) {
-        int *lb = label + (size_t)f * H * W;
-        const int r = uf_find(lb, lb[y * W + x]);
-        if (count[(size_t)f * H * W + r] <= max_size) v = new_val;
+        const size_t base = o / npix_frame * npix_frame;
+        const int *lb = label + base;
+        int r = lb[o - base], pr = lb[r];
+        while (pr != r) {
+            r = pr;
+            pr = lb[r];
+        }
+        if (size[base + r] <= max_size) v = new_val;
     }
     float fv = (float)v;                       // rsgm.py:286
     if (subpixel && fv != 0.0f) fv = fdc[o];   // rsgm.py:289-290
@@ -3295,22 +3361,26 @@ __global__ void __launch_bounds__(64 * BGC_RL) interp_bg_cols_kernel(float *__re
 int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
                      float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out)
 {
-    int *runlen = (int *)fd; // scratch [B*H*W] ints
-    dim3 grid((g.W + 255) / 256, g.H, g.B);
+    (void)fd;
     const size_t n = (size_t)g.B * g.H * g.W;
     if (g.W > 8192) { vppx_set_error("frame width %d > 8192 is not supported by the post-processing kernels", g.W); return VPPX_E_UNSUPPORTED; }
-    crop_lrc_kernel<<<grid, 256, 0, ctx->stream>>>(dl_pad, dr_pad, fdc, fd8, g.H, g.W, g.Hp, g.Wp, g.pad_t, g.pad_l);
-    VPPX_CHECK_LAUNCH();
-    VPPX_HIP(hipMemsetAsync(lcount, 0, n * sizeof(int), ctx->stream));
-    VPPX_HIP(hipMemsetAsync(runlen, 0, n * sizeof(int), ctx->stream));
-    speckle_runs_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(fd8, label, runlen, g.H, g.W, 0, 10);
-    VPPX_CHECK_LAUNCH();
-    speckle_vunion_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, g.H, g.W, 0, 10);
-    VPPX_CHECK_LAUNCH();
-    speckle_count_kernel<<<grid, 256, 0, ctx->stream>>>(label, runlen, lcount, g.H, g.W);
-    VPPX_CHECK_LAUNCH();
-    speckle_apply_kernel<<<grid, 256, 0, ctx->stream>>>(fd8, label, lcount, fdc, out, g.H, g.W, 0, 200, subpixel);
-    VPPX_CHECK_LAUNCH();
+    {
+        const int nby = (g.H - 1) / SPK_TH, nbx = (g.W - 1) / SPK_TW;
+        const size_t npf = (size_t)g.H * g.W;
+        speckle_tile_kernel<<<dim3((g.W + SPK_TW - 1) / SPK_TW, (g.H + SPK_TH - 1) / SPK_TH, g.B), 256, 0, ctx->stream>>>(
+            dl_pad, dr_pad, fdc, fd8, label, lcount, g.H, g.W, g.Hp, g.Wp, g.pad_t, g.pad_l, 0, 10);
+        VPPX_CHECK_LAUNCH();
+        const int nlinks = nby * g.W + nbx * g.H;
+        if (nlinks > 0) {
+            speckle_border_kernel<<<dim3((nlinks + 255) / 256, g.B), 256, 0, ctx->stream>>>(fd8, label, g.H, g.W, 0, 10);
+            VPPX_CHECK_LAUNCH();
+        }
+        const unsigned nblk = (unsigned)((n + 255) / 256);
+        speckle_total_kernel<<<nblk, 256, 0, ctx->stream>>>(label, lcount, npf, g.B);
+        VPPX_CHECK_LAUNCH();
+        speckle_apply_kernel<<<nblk, 256, 0, ctx->stream>>>(fd8, label, lcount, fdc, out, npf, g.B, 0, 200, subpixel);
+        VPPX_CHECK_LAUNCH();
+    }
     if (g.W <= 2048) interp_bg_rows_kernel<8><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
     else interp_bg_rows_kernel<32><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
     VPPX_CHECK_LAUNCH();

@@ -800,6 +800,27 @@ extern "C" int vppx_rsgm_dev(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int 
     return rsgm_core(ctx, *p, g, left, left_vpp, right_vpp, disp_out, hints, validhints);
 }
 
+extern "C" int vppx_rsgm_post_dev(vppx_ctx *ctx, int B, int H, int W, const float *disp_l_pad, const float *disp_r_pad,
+                                  int subpixel, float *disp_out)
+{
+    int rc;
+    VPPX_ENTER(ctx);
+    if (!disp_l_pad || !disp_r_pad || !disp_out) { vppx_set_error("vppx_rsgm_post: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_frames(B, H, W, 1))) return rc;
+    RsgmGeom g;
+    make_geom(B, H, W, 1, 64, g);
+    const size_t np = (size_t)B * H * W;
+    float *fdc, *fdscr;
+    u8 *fd8;
+    int *label, *lcount;
+    if ((rc = ws_get(ctx, WS_FD, np, &fdscr))) return rc;
+    if ((rc = ws_get(ctx, WS_FDC, np, &fdc))) return rc;
+    if ((rc = ws_get(ctx, WS_FD8, np, &fd8))) return rc;
+    if ((rc = ws_get(ctx, WS_LABEL, np, &label))) return rc;
+    if ((rc = ws_get(ctx, WS_LCOUNT, np, &lcount))) return rc;
+    return rsgm_launch_post(ctx, g, disp_l_pad, disp_r_pad, fdscr, fdc, fd8, label, lcount, subpixel, disp_out);
+}
+
 extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,
                               const uint8_t *left_vpp, const uint8_t *right_vpp, const float *hints,
                               const float *validhints, float *disp_out)

@@ -77,6 +77,24 @@ class Engine:
                                           _ptr(right_vpp), None, None, _ptr(out)))
         return out
 
+    def rsgm_post(self, disp_l_pad, disp_r_pad, h, w, subpixel=True, out=None):
+        """Stage API: the post-processing of compute_rsgm (rsgm.py:275-292) on the padded left / right disparity maps
+        [B, Hp, Wp] (Hp, Wp = h, w rounded up to multiples of 16): crop, left/right check, astype(uint8), filterSpeckles(0, 200,
+        10), sub-pixel restore, _interpolate_background.  Returns [B, h, w] float32."""
+        torch = self.torch
+        self._chk(disp_l_pad, torch.float32, 3, "disp_l_pad")
+        B, Hp, Wp = disp_l_pad.shape
+        self._chk(disp_r_pad, torch.float32, 3, "disp_r_pad", disp_l_pad.shape)
+        if (Hp, Wp) != (-(-int(h) // 16) * 16, -(-int(w) // 16) * 16):
+            raise ValueError("padded maps must be [B, ceil16(h), ceil16(w)]")
+        if out is None:
+            out = torch.empty((B, int(h), int(w)), dtype=torch.float32, device=self.device)
+        self._chk(out, torch.float32, 3, "out", (B, int(h), int(w)))
+        self._bind_stream()
+        _lib.check(self.lib.vppx_rsgm_post_dev(self.ctx.handle, B, int(h), int(w), _ptr(disp_l_pad), _ptr(disp_r_pad),
+                                               int(bool(subpixel)), _ptr(out)))
+        return out
+
     def vpp_rsgm(self, left, right, hints, g_occ=None, out=None, l_vpp=None, r_vpp=None, seed=1, vpp_kw=None,
                  rsgm_kw=None, occ_out=None, inputs_ready=None):
         """The whole hot path for a batch: one call, no host round trips, no synchronisation.
