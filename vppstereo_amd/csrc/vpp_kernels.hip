@@ -724,27 +724,32 @@ __global__ void __launch_bounds__(64) apply_r_hint_kernel(VppK k)
     }
 }
 
+// (grid: a bounded number of blocks per frame that stride over the frame's (row, 256-column block) pairs: a sparse frame,
+// the common case, costs a few hundred blocks that exit at once instead of one block per 256 pixels)
 __global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int yp = blockIdx.y, f = blockIdx.z;
+    const int f = blockIdx.y;
     const int W = k.W, H = k.H;
-    if (q >= W) return;
     if (!r_pixel_driven(k, f)) return; // sparse frame: apply_r_hint_kernel did everything
-    const size_t pidx = ((size_t)f * H + yp) * W + q;
-    const int n = k.rcnt[pidx];
-    if (n == 0) return;
-    if (n <= RLCAP) {
-        u32 ids[RLCAP];
-        r_load_list(k, pidx, ids);
-        r_replay_list(k, f, yp, q, pidx, n, ids);
-        return;
+    const int nxb = (W + 255) / 256;
+    for (int t = blockIdx.x; t < nxb * H; t += gridDim.x) {
+        const int yp = t / nxb, q = (t % nxb) * 256 + threadIdx.x;
+        if (q >= W) continue;
+        const size_t pidx = ((size_t)f * H + yp) * W + q;
+        const int n = k.rcnt[pidx];
+        if (n == 0) continue;
+        if (n <= RLCAP) {
+            u32 ids[RLCAP];
+            r_load_list(k, pidx, ids);
+            r_replay_list(k, f, yp, q, pidx, n, ids);
+            continue;
+        }
+        u8 *px = k.r + pidx * k.C;
+        u8 R[4] = {0, 0, 0, 0};
+        for (int j = 0; j < k.C; j++) R[j] = px[j];
+        r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
+        for (int j = 0; j < k.C; j++) px[j] = R[j];
     }
-    u8 *px = k.r + pidx * k.C;
-    u8 R[4] = {0, 0, 0, 0};
-    for (int j = 0; j < k.C; j++) R[j] = px[j];
-    r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
-    for (int j = 0; j < k.C; j++) px[j] = R[j];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -916,11 +921,8 @@ __global__ void __launch_bounds__(64) apply_l_heavy_kernel(VppK k)
 // phase B visits only those (a wave iterates max-count times, not (2n+1)^2 times).
 // NWIN = 0: generic loop for larger patches.
 template <int NWIN>
-__global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
+__device__ __forceinline__ void apply_l_pixel(const VppK &k, int f, int yp, int xp)
 {
-    const int xp = blockIdx.x * blockDim.x + threadIdx.x;
-    const int yp = blockIdx.y, f = blockIdx.z;
-    if (xp >= k.W) return;
     const int W = k.W, H = k.H;
     u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
@@ -929,7 +931,6 @@ __global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
     u8 L[4] = {0, 0, 0, 0};
     if constexpr (NWIN > 0) {
         constexpr int n = (NWIN - 1) / 2;
-        if (!l_pixel_driven(k, f, NWIN * NWIN)) return; // sparse frame: apply_l_hint_kernel does it
         unsigned long long mask = 0;
         float gw[NWIN * NWIN];
 #pragma unroll
@@ -967,6 +968,18 @@ __global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
     }
     if (touched)
         for (int j = 0; j < k.C; j++) px[j] = L[j];
+}
+// (grid: a bounded number of blocks per frame striding over its (row, 256-column block) pairs, like apply_r_kernel)
+template <int NWIN>
+__global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
+{
+    const int f = blockIdx.y;
+    if (NWIN > 0 && !l_pixel_driven(k, f, NWIN * NWIN)) return; // sparse frame: apply_l_hint_kernel does it
+    const int nxb = (k.W + 255) / 256;
+    for (int t = blockIdx.x; t < nxb * k.H; t += gridDim.x) {
+        const int yp = t / nxb, xp = (t % nxb) * 256 + threadIdx.x;
+        if (xp < k.W) apply_l_pixel<NWIN>(k, f, yp, xp);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1614,7 +1627,9 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
                                                                       qoff_for(p.rand_offset), tab, nblk);
     VPPX_CHECK_LAUNCH();
     stage_mark(ctx, ST_VPP_RAND);
-    dim3 grid((g.W + 255) / 256, g.H, g.B);
+    // the pixel-driven kernels (dense frames): a bounded grid per frame, strided (a sparse frame's blocks exit at once)
+    const int npairs = ((g.W + 255) / 256) * g.H;
+    dim3 grid((unsigned)(npairs < 1024 ? npairs : 1024), g.B);
     if ((rc = ws_get(ctx, WS_RCNT, npx, &k.rcnt))) return rc;
     if ((rc = ws_get(ctx, WS_RLIST, npx * RLCAP, &k.rlist))) return rc;
 
