@@ -310,3 +310,20 @@ def test_mixed_density_batch_uses_both_thread_mappings(kw):
         assert n == nh[f], (f, kw)
         assert np.array_equal(a0, lg[f]), (f, dens[f], kw)
         assert np.array_equal(b0, rg[f]), (f, dens[f], kw)
+
+
+@pytest.mark.parametrize("h,w,p", [(61, 97, 0.05), (135, 240, 0.03), (8, 8, 0.5), (40, 700, 0.3), (270, 480, 0.01)])
+def test_occlusion_mask_single_launch_kernel(h, w, p):
+    """The mask alone (Engine.occlusion_heuristic, what the hot path takes: occ_rows_kernel, rows in LDS) against the oracle,
+    default and other window / weight / threshold parameters, dense and sparse hints, several frames per call."""
+    import torch
+    from vppstereo_amd.engine import Engine
+    eng = Engine()
+    b = synth.make_batch(3, h, w, 64, p, seed=h + w)
+    hints = torch.from_numpy(np.ascontiguousarray(b["hints"])).to(eng.device)
+    for kw in (dict(), dict(rx=5, ry=3), dict(rx=13, ry=11, l=1.5, g=0.3), dict(rx=1, ry=1), dict(th_conf=0.25, th_filter=0.1),
+               dict(rx=9, ry=7, l=0.5, g=0.9, th_conf=2)):
+        got = eng.occlusion_heuristic(hints, **kw).cpu().numpy()
+        for f in range(3):
+            want = oracle.occlusion_heuristic(b["hints"][f], **kw)[1]
+            assert np.array_equal(got[f], want), (kw, f, int((got[f] != want).sum()))
