@@ -133,7 +133,9 @@ int vppx_set_stream_legacy(vppx_ctx *ctx);
 
 /* Cross-call pipelining for streams of batches through vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev: with `on`, the front
  * stage of a call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the PREVIOUS call's
- * aggregation is done, i.e. next to that call's sum / WTA and post kernels.  Safe by construction:
+ * aggregation is done, i.e. next to that call's sum / WTA and post kernels (calls of fewer than 8 frames leave most of the
+ * GPU idle during their aggregation: there the next front stage starts as soon as the previous one has delivered its
+ * results, next to that aggregation; the gray / census images exist twice for this).  Safe by construction:
  *   - outputs keep the launch stream's order: the launch stream waits for the front stage, and everything the front stage
  *     produces for the caller (conf_out, l_vpp, r_vpp) is computed into library-owned buffers and copied to the caller's
  *     memory ON THE LAUNCH STREAM -- the front stream never writes caller memory, so buffers allocated per call by a
