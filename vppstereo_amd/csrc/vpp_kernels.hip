@@ -499,7 +499,16 @@ __device__ __forceinline__ void r_apply_hint(const VppK &k, int f, int yp, int y
     const float cc = h.occ ? k.c_occ : k.c;
     const int xd0 = h.x - h.d0, xd1 = h.x - h.d1, xd = h.x - h.d;
     const int xw_hi = min(h.nk, xw_lim);
-    for (int xw = -h.nk; xw <= xw_hi; xw++) {
+    // The reference walks xw = -n_k .. n_k; only the (at most two) offsets whose target is column q act on this pixel:
+    // xd0 + xw == q, xd1 + xw == q (one apart at most, pyx:110,117), or without interpolation xd + xw == q / q - W (the
+    // wraparound write, pyx:113,121).  They are visited in ascending order, as the loop would.
+    const int xa = k.interp ? q - xd0 : q - W - xd;
+    const int xb = k.interp ? q - xd1 : q - xd;
+#pragma unroll 1
+    for (int s2 = 0; s2 < 2; s2++) {
+        const int xw = s2 == 0 ? xa : xb;
+        if (s2 == 1 && xb == xa) break;
+        if (xw < -h.nk || xw > xw_hi) continue;
         const int xx = h.x + xw;
         if (xx < 0 || xx > W - 1) continue;                 // pyx:99
         if (k.use_bil && !gate_pass(k, f, h.g, yp, xx)) continue;
