@@ -309,52 +309,114 @@ struct PgcArgs {
     u32 *census[2];
     int B, H, W, C, Hp, Wp, pad_t, pad_l;
 };
+// nbr - centre of two bytes picked out of two dwords (SDWA): the sign bit says nbr < centre
+template <int BA, int BB>
+__device__ __forceinline__ u32 sub_bytes(u32 a, u32 b)
+{
+    u32 d;
+#define VPPX_SUBB(A, B)                                                                                                   \
+    if constexpr (BA == A && BB == B)                                                                                     \
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #A " src1_sel:BYTE_" #B      \
+            : "=v"(d)                                                                                                     \
+            : "v"(a), "v"(b));
+    VPPX_SUBB(0, 0) VPPX_SUBB(0, 1) VPPX_SUBB(0, 2) VPPX_SUBB(0, 3) VPPX_SUBB(1, 0) VPPX_SUBB(1, 1) VPPX_SUBB(1, 2) VPPX_SUBB(1, 3)
+    VPPX_SUBB(2, 0) VPPX_SUBB(2, 1) VPPX_SUBB(2, 2) VPPX_SUBB(2, 3) VPPX_SUBB(3, 0) VPPX_SUBB(3, 1) VPPX_SUBB(3, 2) VPPX_SUBB(3, 3)
+#undef VPPX_SUBB
+    return d;
+}
+// census code of pixel P (0..3) of a thread's group from the five window rows (two dwords each: columns -2 .. +5 of the group)
+template <int P>
+__device__ __forceinline__ u32 census_of(const u32 (&w)[5][2])
+{
+    constexpr int CI = P + 2; // the centre's byte among the 8
+    u32 v = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; dy++) {
+        // (v << 1) | (nbr < centre), rsgm.py:25-26 -> census5x5_SSE bit order: rows top to bottom, columns left to right
+#define VPPX_CBIT(DX)                                                                                                     \
+    if (!(dy == 2 && DX == 2)) {                                                                                          \
+        constexpr int NI = P + DX;                                                                                        \
+        v = __builtin_amdgcn_alignbit(v, sub_bytes<(NI & 3), (CI & 3)>(w[dy][NI >> 2], w[2][CI >> 2]), 31);              \
+    }
+        VPPX_CBIT(0) VPPX_CBIT(1) VPPX_CBIT(2) VPPX_CBIT(3) VPPX_CBIT(4)
+#undef VPPX_CBIT
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(256) pad_gray_census_kernel(PgcArgs a)
 {
-    constexpr int LW = PGC_TX + 4, LH = PGC_TY + 4, LP = LW + 4; // tile with halo, row pitch
-    __shared__ u8 tile[LH * LP];
+    // tile with halo: LDS column lx holds padded column x0 - 2 + lx, row ly padded row y0 - 2 + ly; the pitch is a multiple of
+    // 4 so that the 8 window columns of a group of 4 pixels are two aligned dwords
+    constexpr int LW = PGC_TX + 4, LH = PGC_TY + 4, LP = LW + 4;
+    static_assert(LW % 4 == 0 && LP % 4 == 0, "groups of four columns");
+    __shared__ __attribute__((aligned(16))) u8 tile[LH * LP];
     const int set = blockIdx.z / a.B, f = blockIdx.z % a.B;
     const int x0 = blockIdx.x * PGC_TX, y0 = blockIdx.y * PGC_TY;
     const u8 *img = set == 0 ? a.img[0] : (set == 1 ? a.img[1] : a.img[2]);
-    for (int i = threadIdx.x; i < LW * LH; i += 256) {
-        const int ly = i / LW, lx = i % LW;
-        int y = y0 + ly - 2, x = x0 + lx - 2;
-        y = min(max(y, 0), a.Hp - 1); // (outside the padded image only the census border reads, and that is zero anyway)
-        x = min(max(x, 0), a.Wp - 1);
-        const int sy = reflect_idx(y - a.pad_t, a.H), sx = reflect_idx(x - a.pad_l, a.W);
-        const u8 *s = img + (((size_t)f * a.H + sy) * a.W + sx) * a.C;
-        u32 v;
-        if (a.C == 3) v = (s[0] * 9798u + s[1] * 19235u + s[2] * 3735u + 16384u) >> 15;
-        else v = s[0];
-        tile[ly * LP + lx] = (u8)v;
+    // source rectangle of the tile without any reflection or clamping?  (all but the tiles on the frame's border)
+    const int sy0 = y0 - 2 - a.pad_t, sx0 = x0 - 2 - a.pad_l;
+    const bool interior = sy0 >= 0 && sy0 + LH <= a.H && sx0 >= 0 && sx0 + LW <= a.W && y0 + PGC_TY + 2 <= a.Hp && x0 + PGC_TX + 2 <= a.Wp;
+    if (interior && (a.C == 3 || a.C == 1)) {
+        // four pixels per thread and step: 12 (or 4) contiguous source bytes, gray by two byte dot products per pixel
+        // ((R * 9798 + G * 19235 + B * 3735 + 16384) >> 15 with the weights split into high and low bytes), one LDS dword
+        for (int gi = threadIdx.x; gi < (LW / 4) * LH; gi += 256) {
+            const int ly = gi / (LW / 4), g4 = gi % (LW / 4);
+            const u8 *sp = img + (((size_t)f * a.H + sy0 + ly) * a.W + sx0 + 4 * g4) * a.C;
+            u32 out;
+            struct __attribute__((packed, aligned(1))) U1 { u32 v; };
+            if (a.C == 3) {
+                const u32 w0 = ((const U1 *)sp)->v, w1 = ((const U1 *)(sp + 4))->v, w2 = ((const U1 *)(sp + 8))->v;
+                const u32 p0 = w0, p1 = __builtin_amdgcn_alignbyte(w1, w0, 3), p2 = __builtin_amdgcn_alignbyte(w2, w1, 2), p3 = w2 >> 8;
+                constexpr u32 WL = 0x00972346u, WH = 0x000E4B26u; // low / high bytes of {9798, 19235, 3735}, fourth byte ignored
+                u32 gq[4];
+                const u32 px[4] = {p0, p1, p2, p3};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    gq[q] = (__builtin_amdgcn_udot4(px[q], WL, 16384u, false) + (__builtin_amdgcn_udot4(px[q], WH, 0u, false) << 8)) >> 15;
+                out = gq[0] | (gq[1] << 8) | (gq[2] << 16) | (gq[3] << 24);
+            } else {
+                out = ((const U1 *)sp)->v;
+            }
+            *(u32 *)(tile + ly * LP + 4 * g4) = out;
+        }
+    } else {
+        for (int i = threadIdx.x; i < LW * LH; i += 256) {
+            const int ly = i / LW, lx = i % LW;
+            int y = y0 + ly - 2, x = x0 + lx - 2;
+            y = min(max(y, 0), a.Hp - 1); // (outside the padded image only the census border reads, and that is zero anyway)
+            x = min(max(x, 0), a.Wp - 1);
+            const int sy = reflect_idx(y - a.pad_t, a.H), sx = reflect_idx(x - a.pad_l, a.W);
+            const u8 *s = img + (((size_t)f * a.H + sy) * a.W + sx) * a.C;
+            u32 v;
+            if (a.C == 3) v = (s[0] * 9798u + s[1] * 19235u + s[2] * 3735u + 16384u) >> 15;
+            else v = s[0];
+            tile[ly * LP + lx] = (u8)v;
+        }
     }
     __syncthreads();
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int x = x0 + tx;
-    if (x >= a.Wp) return;
+    // one group of four pixels of one tile row per thread
+    const int ly = threadIdx.x >> 4, g4 = threadIdx.x & 15;
+    const int x = x0 + 4 * g4, y = y0 + ly;
+    if (x >= a.Wp || y >= a.Hp) return; // (Wp is a multiple of 16: a group is inside or outside as a whole)
+    const size_t o = ((size_t)f * a.Hp + y) * a.Wp + x;
+    u32 w[5][2];
 #pragma unroll
-    for (int r = 0; r < PGC_TY / 4; r++) {
-        const int ly = ty + 4 * r, y = y0 + ly;
-        if (y >= a.Hp) break;
-        const size_t o = ((size_t)f * a.Hp + y) * a.Wp + x;
-        const u8 *c = tile + (ly + 2) * LP + (tx + 2);
-        if (set == 0) {
-            a.gray0[o] = c[0];
-            continue;
-        }
-        u32 v = 0;
-        if (y >= 2 && y < a.Hp - 2 && x >= 2 && x < a.Wp - 2) {
-            const u32 cv = c[0];
-#pragma unroll
-            for (int dy = -2; dy <= 2; dy++)
-#pragma unroll
-                for (int dx = -2; dx <= 2; dx++) {
-                    if (dy == 0 && dx == 0) continue;
-                    v = (v << 1) | (u32)(c[dy * LP + dx] < cv);
-                }
-        }
-        (set == 1 ? a.census[0] : a.census[1])[o] = v;
+    for (int dy = 0; dy < 5; dy++) {
+        const u32 *rp = (const u32 *)(tile + (ly + dy) * LP + 4 * g4);
+        w[dy][0] = rp[0];
+        w[dy][1] = rp[1];
     }
+    if (set == 0) {
+        *(u32 *)(a.gray0 + o) = __builtin_amdgcn_alignbyte(w[2][1], w[2][0], 2); // the four centre pixels
+        return;
+    }
+    u32 c[4] = {census_of<0>(w), census_of<1>(w), census_of<2>(w), census_of<3>(w)};
+    const bool yin = y >= 2 && y < a.Hp - 2;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (!(yin && x + q >= 2 && x + q < a.Wp - 2)) c[q] = 0;
+    *(u32x4 *)((set == 1 ? a.census[0] : a.census[1]) + o) = u32x4{c[0], c[1], c[2], c[3]};
 }
 
 int rsgm_launch_pad_gray_census(vppx_ctx *ctx, const RsgmGeom &g, const u8 *left, const u8 *left_vpp, const u8 *right_vpp, u8 *gray_left,
