@@ -2905,10 +2905,21 @@ int rsgm_launch_wta_right(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16
 // ---------------------------------------------------------------------------------------
 // median3x3 on float32 (call sites rsgm.py:145,173): exact median inside, border copied.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void cswap(float &a, float &b)
+// Median of nine as order statistics of the three sorted columns: med3(max of the minima, med of the medians, min of the
+// maxima) -- 13 three-operand min / med / max instructions (v_min3_f32, v_med3_f32, v_max3_f32) instead of a 19-exchange
+// network's 38.  The median is one of the nine values whatever the method, so the bits are the same.
+__device__ __forceinline__ float median9(const float (&v)[9])
 {
-    const float lo = fminf(a, b), hi = fmaxf(a, b);
-    a = lo; b = hi;
+    float lo[3], md[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float a = v[c], b = v[3 + c], d = v[6 + c];
+        lo[c] = fminf(fminf(a, b), d);
+        md[c] = __builtin_amdgcn_fmed3f(a, b, d);
+        hi[c] = fmaxf(fmaxf(a, b), d);
+    }
+    return __builtin_amdgcn_fmed3f(fmaxf(fmaxf(lo[0], lo[1]), lo[2]), __builtin_amdgcn_fmed3f(md[0], md[1], md[2]),
+                                   fminf(fminf(hi[0], hi[1]), hi[2]));
 }
 __global__ void __launch_bounds__(256) median3x3_kernel(const float *__restrict__ src, float *__restrict__ dst, int Hp, int Wp)
 {
@@ -2926,15 +2937,7 @@ __global__ void __launch_bounds__(256) median3x3_kernel(const float *__restrict_
         for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
             for (int dx = -1; dx <= 1; dx++) v[(dy + 1) * 3 + dx + 1] = s[(size_t)(y + dy) * Wp + x + dx];
-        // 19-comparator median-of-9 network
-        cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
-        cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
-        cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
-        cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
-        cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
-        cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
-        cswap(v[4], v[2]);
-        out = v[4];
+        out = median9(v);
     }
     dst[((size_t)f * Hp + y) * Wp + x] = out;
 }
@@ -3016,14 +3019,7 @@ __global__ void __launch_bounds__(256) median_interp_clip_kernel(ImgSet io, int 
             for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
                 for (int dx = -1; dx <= 1; dx++) v[(dy + 1) * 3 + dx + 1] = s[(size_t)(y + dy) * Wp + x + dx];
-            cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
-            cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
-            cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
-            cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
-            cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
-            cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
-            cswap(v[4], v[2]);
-            out = v[4];
+            out = median9(v);
         }
         s_med[x] = out;
     }

@@ -1812,6 +1812,38 @@ __global__ void __launch_bounds__(256) occ_conf_kernel(const float *__restrict__
     u8 cf = valid ? 0 : 1;
     const int nyw = 2 * ry + 2, nwin = (2 * rx + 1) * nyw; // centre = (y - yw, x - xw), xw in [-rx,rx], yw in [-ry-1,ry] (:149)
     unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    if (nwin <= 256) {
+        // a lane's window positions (lane, lane + 64, ...) and their distance weights do not depend on the pixel under
+        // test: worked out once (the integer divisions and four of the five float64 operations of every test)
+        int xwj[4], ywj[4];
+        double wgj[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int kpos = lane + 64 * j;
+            xwj[j] = kpos / nyw - rx;
+            ywj[j] = kpos % nyw - ry - 1;
+            wgj[j] = __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xwj[j])), __dmul_rn(__dsub_rn(1.0, g), (double)abs(ywj[j]))));
+            if (kpos >= nwin) ywj[j] = 0x40000000; // never inside the frame
+        }
+        const int nj = (nwin + 63) >> 6;
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int xs = __builtin_amdgcn_readlane(x, src);
+            const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn), src));
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j >= nj) break; // uniform
+                const int yc = y - ywj[j], xc = xs - xwj[j];
+                if (yc < 0 || yc > H - 1 || xc < 0 || xc > W - 1) continue;
+                const float dc = om[(size_t)yc * W + xc];
+                if (dc > 0 && ds < dc) hit = hit || (__dsub_rn((double)__fsub_rn(dc, ds), wgj[j]) > th);
+            }
+            if (__builtin_amdgcn_ballot_w64(hit) != 0 && lane == src) cf = 1;
+        }
+        todo = 0;
+    }
     while (todo) {
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
