@@ -156,6 +156,10 @@ def vpp(left, right, gt, wsize=3, wsizeAgg_x=64, wsizeAgg_y=3, left2right=True, 
         return lc, rc
     dmin = gt[gt > 0].min()
     dmax = gt[gt > 0].max()
+    if use_distance_patch and not dmax > dmin:
+        # _get_patch_size_based_on_distance (vpp_standalone.py:6-11) is @njit with numba's default error model: the float
+        # division by d_max - d_min == 0 raises there, for the first hint it meets
+        raise ZeroDivisionError("division by zero")
     if len(lc.shape) == 3 and lc.shape[2] == 3:
         gray_context = rgb2gray(lc, bgr=True)
     else:

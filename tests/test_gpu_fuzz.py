@@ -32,8 +32,15 @@ def test_vpp_random_parameters(seed):
     if rng.integers(5) == 0:
         kw.update(method="maxDistance", wsizeAgg_x=int(rng.choice([5, 17, 64])), wsizeAgg_y=int(rng.choice([1, 3])))
         kw["wsize"] = min(kw["wsize"], 5)
-    if kw["use_distance_patch"] and not (fr["hints"] > 0).any():
-        kw["use_distance_patch"] = False   # dmax == dmin: the reference divides by zero
+    pos = fr["hints"][fr["hints"] > 0]
+    if kw["use_distance_patch"] and pos.size and not pos.max() > pos.min():
+        # one distinct hint value: the reference divides by dmax - dmin == 0 under numba's python error model
+        oracle.init_rand(seed)
+        with pytest.raises(ZeroDivisionError):
+            oracle.vpp(fr["left"], fr["right"], fr["hints"], **kw)
+        with pytest.raises(ZeroDivisionError):
+            vpp_standalone.vpp(fr["left"], fr["right"], fr["hints"], **kw)
+        return
     l, r = (fr["left"][..., 0], fr["right"][..., 0]) if (C3 == 1 and rng.integers(2)) else (fr["left"], fr["right"])
     oracle.init_rand(seed)
     lo, ro = oracle.vpp(l, r, fr["hints"], **kw)
