@@ -24,6 +24,19 @@ if engines is not None:
             ff.test_fused_layout_equals_eight_path_layout(engines, s)
         except Exception as e:  # noqa
             fails.append(("fused", s, str(e)[:200]))
+import numpy as np
+import tests.test_gpu_post as tp
+from vppstereo_amd.engine import Engine
+_eng = Engine()
+for s in range(first, first + n):
+    rng = np.random.default_rng(s)
+    h, w = int(rng.integers(5, 160)), int(rng.integers(5, 330))
+    lo = int(rng.integers(1, 12))
+    maps = [tp._blocks(h, w, rng, lo, lo + int(rng.integers(2, 30))) for _ in range(int(rng.integers(1, 4)))]
+    try:
+        tp._run(_eng, maps, h, w, rng, subpixel=bool(rng.integers(2)), flip=float(rng.choice([0.0, 0.05, 0.3])))
+    except Exception as e:  # noqa
+        fails.append(("post", s, str(e)[:200]))
 print("seeds %d..%d: %d failures in %.0f s" % (first, first + n - 1, len(fails), time.time() - t0), flush=True)
 for f in fails[:20]:
     print(f)
