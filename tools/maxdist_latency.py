@@ -4,7 +4,7 @@ import synth
 from vppstereo_amd.engine import Engine
 eng = Engine()
 dev = eng.device
-for B in (1, 8):
+for B in (1, 8, 32):
     b = synth.make_batch(min(B,4), 540, 960, 192, 0.03, seed=1234)
     idx=[i%min(B,4) for i in range(B)]
     l = torch.from_numpy(np.ascontiguousarray(b["left"][idx])).to(dev); r = torch.from_numpy(np.ascontiguousarray(b["right"][idx])).to(dev)
