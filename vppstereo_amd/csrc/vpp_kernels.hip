@@ -1644,11 +1644,31 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     const bool split_early = (occ == nullptr) && ctx->stream2 != nullptr;
     const bool split_late = !split_early && r_orig != nullptr && r_orig != r && ctx->stream2 != nullptr;
     const bool split = split_early || split_late;
+    // pixels with an occluded hint in their window: second pass (from 8 frames per call on; for a single frame the extra
+    // launch costs more than the divergence it removes: 0.70 -> 0.77 ms per frame)
+    const bool two_pass = occ != nullptr && !k.discard && k.n <= 3 && g.B >= 8;
+    if (!two_pass) k.lwork = nullptr; // (rowscan_kernel has zeroed the work-list counter)
+    // With two passes the first one never looks at R (it defers every pixel that would): it starts right away on the side
+    // stream, next to the list build; only the second pass waits for the lists.
+    const bool light_early = two_pass && split_late;
+    auto launch_l_hint = [&](hipStream_t st) {
+        switch (k.n) { // sparse frames (each frame picks one of the two mappings on the device)
+        case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
+        case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
+        case 2: apply_l_hint_kernel<5><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
+        case 3: apply_l_hint_kernel<7><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
+        default: break;
+        }
+    };
     hipStream_t ls = ctx->stream;
-    if (split_early) {
+    if (split_early || light_early) {
         VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         ls = ctx->stream2;
+    }
+    if (light_early) {
+        launch_l_hint(ls);
+        VPPX_CHECK_LAUNCH();
     }
     VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
     rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
@@ -1658,18 +1678,10 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         ls = ctx->stream2;
     }
-    // pixels with an occluded hint in their window: second pass (from 8 frames per call on; for a single frame the extra
-    // launch costs more than the divergence it removes: 0.70 -> 0.77 ms per frame)
-    const bool two_pass = occ != nullptr && !k.discard && k.n <= 3 && g.B >= 8;
-    if (!two_pass) k.lwork = nullptr; // (rowscan_kernel has zeroed the work-list counter)
-    switch (k.n) { // sparse frames (each frame picks one of the two mappings on the device)
-    case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
-    case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
-    case 2: apply_l_hint_kernel<5><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
-    case 3: apply_l_hint_kernel<7><<<dim3(g.H, g.B), 64, 0, ls>>>(k); break;
-    default: break;
+    if (!light_early) {
+        launch_l_hint(ls);
+        VPPX_CHECK_LAUNCH();
     }
-    VPPX_CHECK_LAUNCH();
     if (two_pass) {
         const dim3 hg((unsigned)(g.B * 64 < 4096 ? g.B * 64 : 4096));
         switch (k.n) {
