@@ -1683,7 +1683,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         VPPX_CHECK_LAUNCH();
     }
     if (two_pass) {
-        const dim3 hg((unsigned)(g.B * 64 < 4096 ? g.B * 64 : 4096));
+        const dim3 hg((unsigned)(g.B * 256 < 16384 ? g.B * 256 : 16384)); // (about one deferred pixel per thread at 3 % hints: the replays are latency chains)
         switch (k.n) {
         case 0: apply_l_heavy_kernel<1><<<hg, 64, 0, ls>>>(k); break;
         case 1: apply_l_heavy_kernel<3><<<hg, 64, 0, ls>>>(k); break;
