@@ -2543,7 +2543,8 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
                     sB = sB >= NT ? sB - NT : sB;
                     sB = sB >= NT ? sB - NT : sB;
                     const u32 lane_base = (u32)dbase * TW + (a0 % T);
-                    const int RA = (int)(sA * TS + lane_base), RB = (int)(sB * TS + lane_base) - T; // RB >= -T: guard elements
+                    // (24-bit multiplies: v_mul_lo_u32 is quarter rate)
+                    const int RA = (int)(__umul24(sA, (u32)TS) + lane_base), RB = (int)(__umul24(sB, (u32)TS) + lane_base) - T; // RB >= -T: guard elements
                     const int e_cross = T - (int)(a0 % T); // first element that lies in the next tile
 #pragma unroll
                     for (int i = 0; i < NP; i++) {
@@ -2569,7 +2570,7 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
                         const u32 a = (u32)(g + d);
                         u32 sl = r_slot + a / T;
                         sl = sl >= NT ? sl - NT : sl;
-                        return ring[sl * TS + d * TW + (a % T)];
+                        return ring[__umul24(sl, (u32)TS) + __umul24((u32)d, (u32)TW) + (a % T)];
                     });
                     if (l16 == (j & (GL - 1))) {
                         asm volatile("; keep (right view)");
