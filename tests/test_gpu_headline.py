@@ -387,3 +387,28 @@ def test_pipelined_stream_of_small_batches_starts_the_next_front_stage_early():
     for rep in range(3):
         for i in range(len(batches)):
             assert torch.equal(outs[i][rep], refs[i]), (rep, i, shapes[i])
+
+
+@pytest.mark.parametrize("B", [9, 26])
+def test_full_size_odd_batches_take_the_fused_layout(B):
+    """Any number of frames from 8 on takes the fused layout at full size (the grid is rounded up to whole rounds of 8
+    groups, ghost groups exit): 9 and 26 frames of 540 x 960 x 192, two pipelined steps, equal the 8-path layout bit for bit."""
+    import torch
+    H, W, D = 540, 960, 192
+    eng = _engine()
+    eng.set_pipeline(True)
+    ref = _engine(VPPX_VERT=0)
+    nu = 4
+    b = synth.make_batch(nu, H, W, D, 0.03, seed=99 + B)
+    idx = [(i * 3) % nu for i in range(B)]
+    left, right, hints = (_dev(eng, np.ascontiguousarray(b[k][idx])) for k in ("left", "right", "hints"))
+    outs = [torch.empty((B, H, W), dtype=torch.float32, device=eng.device) for _ in range(2)]
+    for s in range(2):
+        eng.vpp_rsgm(left, right, hints, g_occ="occlusion_heuristic", out=outs[s], seed=5 + s, rsgm_kw=dict(dmax=D))
+    eng.synchronize()
+    assert eng.uses_vert() == 3
+    for s in range(2):
+        want = ref.vpp_rsgm(left, right, hints, g_occ="occlusion_heuristic", seed=5 + s, rsgm_kw=dict(dmax=D))
+        ref.synchronize()
+        assert ref.uses_vert() == 0
+        assert torch.equal(outs[s], want), (B, s)
