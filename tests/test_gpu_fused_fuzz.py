@@ -145,3 +145,35 @@ def test_cross_call_pipelining_keeps_results_and_stream_order():
         torch.cuda.synchronize()
         assert torch.equal(a, refs[0]) and torch.equal(b, refs[0]) and torch.equal(sep, ref_sep), rep
         assert torch.equal(lv, ref_lv) and torch.equal(rv, ref_rv), rep
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_batched_vpp_with_a_mask_random_parameters(engines, seed):
+    """The fused entry point with 8+ frames and an occlusion mask takes the two-pass L side (pixels whose window holds an
+    occluded hint are deferred to a work list) and the early first pass next to the R list build: patterned pairs against the
+    oracle's vpp() frame by frame, over patch sizes, colour modes, blending weights, scan directions and mask densities."""
+    import torch
+    fused = engines[0]
+    rng = np.random.default_rng(7000 + seed)
+    B = int(rng.choice([8, 9, 12]))
+    H, W = int(rng.integers(8, 48)), int(rng.integers(12, 130))
+    dens = float(rng.choice([0.02, 0.1, 0.4]))
+    b = synth.make_batch(B, H, W, 64, dens, seed=7000 + seed)
+    occ = ((rng.random((B, H, W)) < float(rng.choice([0.1, 0.5, 1.0]))) & (b["hints"] > 0)).astype(np.uint8)
+    wsize = int(rng.choice([1, 3, 5, 7, 9]))
+    ref_kw = dict(wsize=wsize, left2right=bool(rng.integers(2)), blending=float(rng.choice([0.4, 0.0, 1.0, 0.73])),
+                  uniform_color=bool(rng.integers(2)), c_occ=float(rng.choice([0.0, 0.2, 1.0])), discard_occ=bool(rng.integers(4) == 0),
+                  interpolate=bool(rng.integers(2)))
+    kw = dict(wsize=wsize, direction=int(ref_kw["left2right"]), c=ref_kw["blending"], uniform_color=int(ref_kw["uniform_color"]),
+              c_occ=ref_kw["c_occ"], discard_occluded=int(ref_kw["discard_occ"]), interpolate=int(ref_kw["interpolate"]))
+    dev = fused.device
+    args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints")]
+    lv = torch.empty_like(args[0])
+    rv = torch.empty_like(args[0])
+    fused.vpp_rsgm(*args, g_occ=torch.from_numpy(occ).to(dev), l_vpp=lv, r_vpp=rv, seed=seed, vpp_kw=kw, rsgm_kw=dict(dmax=64))
+    fused.synchronize()
+    lv, rv = lv.cpu().numpy(), rv.cpu().numpy()
+    for f in range(B):
+        oracle.init_rand(seed + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], g_occ=occ[f], **ref_kw)
+        assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), (seed, f, B, H, W, ref_kw)

@@ -24,6 +24,10 @@ if engines is not None:
             ff.test_fused_layout_equals_eight_path_layout(engines, s)
         except Exception as e:  # noqa
             fails.append(("fused", s, str(e)[:200]))
+        try:
+            ff.test_batched_vpp_with_a_mask_random_parameters(engines, s)
+        except Exception as e:  # noqa
+            fails.append(("batched_vpp", s, str(e)[:200]))
 import numpy as np
 import tests.test_gpu_post as tp
 from vppstereo_amd.engine import Engine
