@@ -448,23 +448,27 @@ def run_rank(args):
                 pending[k].wait()
                 pending[k] = None
 
-    gather_note = None
     if world > 1 and not args.no_gather:
         # RCCL creates its send/recv channels on first use: do that outside the timed region even with --warmup 0.
-        # Should the gather be unusable on this node, every rank agrees to keep its shard local (the data path
-        # has no collective; the gather only delivers results to rank 0) and the line says so.
-        ok = 1
+        # A gather that does not work is an ERROR (non-zero exit status on every rank): a line without the exchange would
+        # look like a multi-GPU result and not be one.  `--no-gather` is the explicit way to time the shards alone.
+        ok, why = 1, ""
         try:
             vdist.gather_disparities_async(outs[0], n_total, dst=0).wait()
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
-            ok = 0
-            print(f"[bench] rank {rank}: result gather failed ({type(e).__name__}: {e}); running without it", file=sys.stderr)
+            ok, why = 0, f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: result gather failed ({why})", file=sys.stderr)
         flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            args.no_gather = True
-            gather_note = "result gather to rank 0 unavailable: shards stay on their ranks"
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"[bench] rank {rank}: all_reduce failed ({type(e).__name__}: {e})", file=sys.stderr)
+        if ok == 0:
+            raise SystemExit(f"[bench] rank {rank}: the result gather to rank 0 does not work on this node ({why or 'another rank failed'}); "
+                             "fix the process group or pass --no-gather to time the shards without the exchange")
 
     def timed(n_steps, fn):
         torch.cuda.synchronize()
@@ -485,6 +489,7 @@ def run_rank(args):
         step()
     drain()
     eng.agg_kernel_ms(0)  # reset: the hipEvent pairs around the aggregation launches of the timed steps only
+    eng.we_kernel_ms(0)
     with SclkSampler(dev_index) as sclk:
         dt_local = timed(args.steps, step)
     eng.status()   # raises if a fused aggregation launch of the timed region lost its lock step (its disparities would be void)
@@ -522,6 +527,7 @@ def run_rank(args):
         # ---- dominant kernel, measured live with hipEvents on its own launch stream ----------
         # average over the launches made INSIDE the timed region (event pairs on the launch stream, ring of 64)
         agg_ms, agg_n = eng.agg_kernel_ms(args.steps)
+        we_ms_in_step, we_n = eng.we_kernel_ms(args.steps)   # the W/E launch of the fused layout inside the timed steps
         layout = eng.uses_vert()   # 0: one launch, eight line-parallel paths; 3: W/E launch + the fused vertical kernel
         fused = layout == 3
         # same kernel re-launched back to back (fused layout: its part of the aggregation only)
@@ -597,7 +603,9 @@ def run_rank(args):
                "convention": f"{agg_bytes} B/cell = SURVEY 8d's 10 B/cell of the 8-path aggregation, pro rata for the paths this launch "
                              f"carries: {round(cells_launch * agg_bytes / 1e9, 3)} GB per launch / kernel_ms vs 8 TB/s (a byte-count "
                              "convention, not a utilisation: see valu and hbm_frac_of_peak)",
-               "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": round(we_ms, 4)} if fused else None),
+               "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": {"in_step": round(we_ms_in_step, 4) if we_n else None,
+                                                                            "launches_timed": we_n, "back_to_back": round(we_ms, 4)}}
+                                               if fused else None),
                "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,
                "sclk_dpm_level_mhz_during_timed_region": sclk_mhz,
                "pmc": pmc}
@@ -647,7 +655,7 @@ def run_rank(args):
         if args.graph:
             result["graph_replays"] = eng.graph_replays()
         if world > 1:
-            result["config"]["result_gather"] = gather_note or ("off" if args.no_gather else "async gather to rank 0, overlapped")
+            result["config"]["result_gather"] = "off (--no-gather)" if args.no_gather else "async gather to rank 0, overlapped"
         if world == 1 and args.cpu_frames > 0:
             gpu_out = local_step(outs[0], use_occ)[: min(args.cpu_frames, n_unique)].cpu().numpy()
             result["cpu_baseline"], epe = cpu_baseline(min(args.cpu_frames, n_unique), gpu_out)

@@ -324,6 +324,8 @@ int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out);
  * on this context, from hipEvent pairs recorded around every launch on its launch stream (ring of
  * 64).  Call after synchronising.  last_n <= 0 resets the launch counter.  n_used may be NULL. */
 int vppx_agg_kernel_ms(vppx_ctx *ctx, int last_n, float *avg_ms, int *n_used);
+/* The same for the W/E launch of the fused layout (line-parallel kernel; the other launch of its aggregation stage). */
+int vppx_we_kernel_ms(vppx_ctx *ctx, int last_n, float *avg_ms, int *n_used);
 /* Frames per launch that vppx_time_aggregate re-runs: vppx_vpp_rsgm_dev splits a batch over
  * internal sub-streams, and the helper times the launches of one part. */
 int vppx_time_aggregate_frames(vppx_ctx *ctx);

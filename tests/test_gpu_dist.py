@@ -33,9 +33,8 @@ def test_two_ranks_sharing_the_device_equal_one_rank(tmp_path, B, H, W, D):
     out_path = str(tmp_path / "gathered.npy")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_rank.py"), str(r), str(world), str(port),
-                               str(B), str(H), str(W), str(D), out_path], env=env) for r in range(world)]
-    # the single-rank run over the same global frames, meanwhile
+    # the single-rank run over the same global frames FIRST: it takes the fused lock-step layout, which wants the GPU's
+    # block slots to itself (the rank processes would compete for them)
     eng = Engine()
     n_total = B * world
     fr = [synth.make_frame(H, W, D, 0.04, seed=77, frame=f) for f in range(n_total)]
@@ -45,6 +44,9 @@ def test_two_ranks_sharing_the_device_equal_one_rank(tmp_path, B, H, W, D):
         want.append(eng.vpp_rsgm(left, right, hints, g_occ="occlusion_heuristic", seed=vdist.frame_seed(5 + step, 0),
                                  rsgm_kw=dict(dmax=D, subpixel=1)).clone())
     eng.synchronize()
+    assert eng.uses_vert() == (3 if n_total >= 8 and D in (128, 192) else 0)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_rank.py"), str(r), str(world), str(port),
+                               str(B), str(H), str(W), str(D), out_path], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     got = np.load(out_path)

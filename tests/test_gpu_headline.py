@@ -101,11 +101,13 @@ def test_forced_lockstep_timeout_is_reported_by_the_same_calls_sync():
     b, args = _small_batch(eng)
     want = ref.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
     ref.synchronize()
-    eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
+    lost = eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
     assert eng.uses_vert() == 3
     with pytest.raises(VppxError, match="lost its lock step") as ei:
         eng.synchronize()
     assert ei.value.code == -8          # VPPX_E_HIP
+    # ... and nothing queued behind the call could have mistaken its output for disparities: it is NaN throughout
+    assert bool(torch.isnan(lost).all())
     assert eng.ctx.lockstep_failures == 1
     eng.synchronize()                   # reported once
     out = eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
@@ -171,6 +173,33 @@ def test_forced_lockstep_timeout_host_entry_point_recovers_by_itself():
     for f in range(B):
         assert np.array_equal(oracle.compute_rsgm(b["left"][f], lv[f], rv[f], dmax=D), out[f]), f
     ctx.status()
+
+
+def test_host_entry_point_does_not_swallow_an_earlier_calls_lost_lock_step():
+    """An asynchronous fused call loses its lock step; the next call is the synchronous vppx_rsgm_host.  The mark belongs
+    to the EARLIER launch, so it must be reported (once) instead of being consumed by the host call's own retry loop."""
+    import torch
+    from vppstereo_amd import _lib
+    D = 192
+    eng = _engine(VPPX_VERT=3, VPPX_V3_SPIN_LIMIT=1)
+    b, args = _small_batch(eng, seed=14)
+    lost = eng.vpp_rsgm(*args, seed=2, rsgm_kw=dict(dmax=D))
+    torch.cuda.synchronize()              # the mark is there, nobody has asked yet
+    lib, ctx = eng.lib, eng.ctx
+    B, H, W = lost.shape
+    lv, rv = np.empty_like(b["left"]), np.empty_like(b["right"])
+    for f in range(B):
+        oracle.init_rand(f)
+        lv[f], rv[f] = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
+    out = np.zeros((B, H, W), np.float32)
+    p = _lib.rsgm_params(dmax=D)
+    call = lambda: lib.vppx_rsgm_host(ctx.handle, C.byref(p), B, H, W, 3, _lib.np_ptr(b["left"]), _lib.np_ptr(lv), _lib.np_ptr(rv),
+                                      None, None, _lib.np_ptr(out))
+    assert call() == -8 and b"lost its lock step" in lib.vppx_last_error()
+    assert ctx.lockstep_failures == 1 and bool(torch.isnan(lost).all())
+    _lib.check(call())                    # reported once; the context has moved to the line-parallel kernel
+    assert lib.vppx_uses_vert(ctx.handle) == 0
+    assert np.array_equal(oracle.compute_rsgm(b["left"][0], lv[0], rv[0], dmax=D), out[0])
 
 
 def test_forced_lockstep_timeout_under_graph_replay():

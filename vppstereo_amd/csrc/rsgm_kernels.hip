@@ -1334,6 +1334,7 @@ struct Vert3Args {
     u8 *sv;     // [2 passes][B][Hp][Wp][D]
     u32 *xbuf;  // [2B groups][nwv][V3_RING rows][2 directions][8 lanes][XW] edge records
     unsigned *err; // host-visible word, set (to the launch serial) when a wave gave up waiting for a neighbour (results void)
+    unsigned *err_dev; // the same in device memory: what the launches queued behind this one look at (void_if_lost_kernel)
     int B, Hp, Wp, p1;
     int nwv, nbg; // waves / blocks per group
     size_t vol_elems;
@@ -1636,7 +1637,10 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         prevI = I;
     }
     store_pend();
-    if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dead && lane == 0 && a.err) {
+        __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.err_dev) __hip_atomic_store(a.err_dev, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1888,7 +1892,10 @@ __global__ void __launch_bounds__(256, 2) sgm_vert4_kernel(Vert3Args a)
         prevI = I;
     }
     store_pend();
-    if (dead && lane == 0 && a.err) __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dead && lane == 0 && a.err) {
+        __hip_atomic_store(a.err, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.err_dev) __hip_atomic_store(a.err_dev, a.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // The lock-step hand-off goes through ONE L2: all blocks of a (frame, pass) group must run on the same XCD, which the
@@ -2028,10 +2035,10 @@ size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D)
 }
 
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
-                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err)
+                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev)
 {
     Vert3Args a;
-    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.xbuf = xbuf; a.err = err;
+    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.xbuf = xbuf; a.err = err; a.err_dev = err_dev;
     a.B = B; a.Hp = Hp; a.Wp = Wp;
     a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (see rsgm_launch_paths); keeps the small-value update in range
     const bool wide = v3_wide(ctx, B, Wp, D);
@@ -3415,6 +3422,26 @@ __global__ void __launch_bounds__(64 * BGC_RL) interp_bg_cols_kernel(float *__re
     const float fv = g[(size_t)first * W + u], lv = g[(size_t)last * W + u];
     for (int v = ry; v < first; v += BGC_RL) g[(size_t)v * W + u] = fv;
     for (int v = last + 1 + ry; v < H; v += BGC_RL) g[(size_t)v * W + u] = lv;
+}
+
+// A fused aggregation launch that lost its lock step leaves void path volumes; the launches behind it cannot know and
+// would turn them into plausible-looking disparities.  Queued right behind the post stage of such a call, this kernel
+// overwrites the call's output with NaN when the device-side error word carries the call's launch serial: whatever
+// consumes the result later on the stream (a gather, torch ops, a copy to the host) sees values no disparity map has.
+__global__ void __launch_bounds__(256) void_if_lost_kernel(float *__restrict__ out, size_t n, const unsigned *__restrict__ err_dev,
+                                                           unsigned serial)
+{
+    if (__hip_atomic_load(err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial) return;
+    const float nan = __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = nan;
+}
+
+int rsgm_launch_void_if_lost(vppx_ctx *ctx, float *out, size_t n, const unsigned *err_dev, unsigned serial)
+{
+    const unsigned nblk = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+    void_if_lost_kernel<<<nblk < 1 ? 1 : nblk, 256, 0, ctx->stream>>>(out, n, err_dev, serial);
+    VPPX_CHECK_LAUNCH();
+    return 0;
 }
 
 int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,

@@ -178,8 +178,10 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (e && atoi(e) > 0) ctx->v3.timeout_ms = atoi(e);
         e = getenv("VPPX_V3_PPW");
         if (e && (atoi(e) == 8 || atoi(e) == 16)) ctx->v3.ppw = atoi(e);
+#ifdef VPPX_EXPERIMENT // measurement builds only (make EXP=1): the shipped library cannot be told to ignore a lost lock step
         e = getenv("VPPX_V3_IGNORE_LOST");
         if (e && atoi(e) > 0) ctx->v3.ignore_lost = true;
+#endif
         e = getenv("VPPX_V3_SPIN_LIMIT");
         if (e && atoi(e) > 0) ctx->v3.spin_limit = (unsigned)atoi(e);
     }
@@ -203,7 +205,10 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->agg_ev_created)
         for (int j = 0; j < 2; j++)
-            for (int i = 0; i < vppx_ctx::AGG_RING; i++) (void)hipEventDestroy(ctx->agg_ev[j][i]);
+            for (int i = 0; i < vppx_ctx::AGG_RING; i++) {
+                (void)hipEventDestroy(ctx->agg_ev[j][i]);
+                (void)hipEventDestroy(ctx->we_ev[j][i]);
+            }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->vert3_err) (void)hipHostFree(ctx->vert3_err);
     if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
@@ -285,6 +290,7 @@ static int lockstep_check(vppx_ctx *ctx)
     const unsigned serial = ctx->vert3_err[0];
     ctx->vert3_err[0] = 0;
     ctx->lockstep_failures++;
+    ctx->lockstep_last_serial = serial;
     if (ctx->v3.ignore_lost) return 0; // measurement only (tools/agg_probe.py: the fused kernel's time without any neighbour wait)
     ctx->vert3_broken = true;
     if (ctx->gexec) {
@@ -474,6 +480,113 @@ static int check_rsgm_params(const VppxRsgmParams &p)
 // 8-path aggregation stage.  which: 0 = everything, 1 = horizontal paths only, 2 = vertical bands
 // only (timing helpers).  Fills vols[] with the volumes the sum/WTA kernel has to add.
 // ---------------------------------------------------------------------------------------
+#ifdef VPPX_EXPERIMENT
+// Experiment hooks (never in the shipped build; `make EXP=1`): what runs right before the W/E launch of a step.
+//   VPPX_EXP_PRE=1  read every census / gray byte the launch will read (warms L2 / MALL / TLB of those)
+//   VPPX_EXP_PRE=2  read one dword per 4 KB of the two volumes the launch writes (TLB of the store stream)
+//   VPPX_EXP_PRE=3  ~0.3 ms of dense VALU work on every CU (clock / power state)
+//   VPPX_EXP_PRE=6  write one dword per 4 KB of the two volumes
+//   VPPX_EXP_ORDER=1 W/E first, fused vertical kernel second (the order of rounds 2-3);  VPPX_EXP_TWICE=1 W/E launched twice (the second is timed)
+__global__ void __launch_bounds__(256) exp_read_kernel(const uint4 *p, size_t n, size_t stride, u32 *sink)
+{
+    u32 acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i * stride];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ void __launch_bounds__(256) exp_write_kernel(u32 *p, size_t n, size_t stride_words)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i * stride_words + 1023] = 0;
+}
+__global__ void __launch_bounds__(256) exp_spin_kernel(u32 *sink, int iters)
+{
+    u32 a = threadIdx.x, b = blockIdx.x;
+    for (int i = 0; i < iters; i++) {
+        a = a * 1664525u + b;
+        b = b * 22695477u + a;
+    }
+    if ((a ^ b) == 0x12345678u) sink[0] = a;
+}
+// One wave that samples (shader-clock counter, 100 MHz wall counter) pairs at a fixed wall period while other launches run:
+// the chip's clock over time across a step (tools/clock_trace.py).
+__global__ void __launch_bounds__(64) exp_clock_trace_kernel(unsigned long long *out, int n, int period_ticks)
+{
+    if (threadIdx.x != 0) return;
+    unsigned long long next = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < n; i++) {
+        unsigned long long w;
+        do {
+            __builtin_amdgcn_s_sleep(8);
+            w = __builtin_amdgcn_s_memrealtime();
+        } while (w < next);
+        out[2 * i] = __builtin_amdgcn_s_memtime();
+        out[2 * i + 1] = w;
+        next = w + (unsigned long long)period_ticks;
+    }
+}
+static hipStream_t g_exp_trace_stream = nullptr;
+static unsigned long long *g_exp_trace_buf = nullptr;
+static int g_exp_trace_n = 0;
+extern "C" int vppx_exp_clock_trace_start(vppx_ctx *ctx, int n, int period_us)
+{
+    VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
+    if (!g_exp_trace_stream) VPPX_HIP(hipStreamCreateWithFlags(&g_exp_trace_stream, hipStreamNonBlocking));
+    if (g_exp_trace_buf) (void)hipFree(g_exp_trace_buf);
+    VPPX_HIP(hipMalloc((void **)&g_exp_trace_buf, (size_t)n * 16));
+    g_exp_trace_n = n;
+    exp_clock_trace_kernel<<<1, 64, 0, g_exp_trace_stream>>>(g_exp_trace_buf, n, period_us * 100);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int vppx_exp_clock_trace_read(vppx_ctx *ctx, unsigned long long *host)
+{
+    VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
+    VPPX_HIP(hipStreamSynchronize(g_exp_trace_stream));
+    VPPX_HIP(hipMemcpy(host, g_exp_trace_buf, (size_t)g_exp_trace_n * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+static int exp_env(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+static int exp_pre_we(vppx_ctx *ctx, const RsgmGeom &g, const u8 *gl, const u32 *cl, const u32 *cr, void *paths, size_t ncell)
+{
+    const int mode = exp_env("VPPX_EXP_PRE");
+    u32 *sink = (u32 *)ctx->ws[WS_P2LUT].p + 200; // never written (the condition cannot hold)
+    const size_t npp = (size_t)g.B * g.Hp * g.Wp;
+    if (mode == 1) {
+        exp_read_kernel<<<2048, 256, 0, ctx->stream>>>((const uint4 *)cl, npp / 4, 1, sink);
+        exp_read_kernel<<<2048, 256, 0, ctx->stream>>>((const uint4 *)cr, npp / 4, 1, sink);
+        exp_read_kernel<<<2048, 256, 0, ctx->stream>>>((const uint4 *)gl, npp / 16, 1, sink);
+    } else if (mode == 2) {
+        exp_read_kernel<<<2048, 256, 0, ctx->stream>>>((const uint4 *)paths, ncell * 2 / 4096, 256, sink);
+    } else if (mode == 3) {
+        exp_spin_kernel<<<4096, 256, 0, ctx->stream>>>(sink, 20000);
+    } else if (mode == 6) {
+        exp_write_kernel<<<2048, 256, 0, ctx->stream>>>((u32 *)paths, ncell * 2 / 4096, 1024);
+    }
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+#endif
+
+static int agg_events_create(vppx_ctx *ctx)
+{
+    if (ctx->agg_ev_created) return 0;
+    for (int j = 0; j < 2; j++)
+        for (int i = 0; i < vppx_ctx::AGG_RING; i++) {
+            VPPX_HIP(hipEventCreate(&ctx->agg_ev[j][i]));
+            VPPX_HIP(hipEventCreate(&ctx->we_ev[j][i]));
+        }
+    ctx->agg_ev_created = true;
+    return 0;
+}
+
 static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, const u8 *gl, const u32 *cl,
                            const u32 *cr, const u16 *lut_d, int maxp2, const void **vols, int *nvol_out,
                            int *elem_bytes_out, int which, const float *hints = nullptr, const float *validhints = nullptr)
@@ -535,7 +648,22 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         // 19 instead of 26 instructions per pixel, bit-exact -- and measured 1.88-2.10 ms (16 rows, 168 VGPRs: 2-3 waves per
         // SIMD cannot cover the walk's dependent chain) and 2.6 ms (8 rows: 96 VGPRs only with spills) against 1.94-2.00.)
         auto launch_we = [&]() -> int {
-            return rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11);
+            // event pairs around this launch too: inside a step it follows a run of small kernels (or the previous step's
+            // post stage) and has been seen to take longer than when it is re-launched back to back
+            const bool timed = !ctx->capturing;
+            if (timed && (rc = agg_events_create(ctx))) return rc;
+            const int slot = (int)(ctx->we_calls % vppx_ctx::AGG_RING);
+#ifdef VPPX_EXPERIMENT
+            if ((rc = exp_pre_we(ctx, g, gl, cl, cr, paths, ncell))) return rc;
+            if (exp_env("VPPX_EXP_TWICE") && (rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11))) return rc;
+#endif
+            if (timed) VPPX_HIP(hipEventRecord(ctx->we_ev[0][slot], ctx->stream));
+            const int r = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, 1, 0x11);
+            if (timed) {
+                VPPX_HIP(hipEventRecord(ctx->we_ev[1][slot], ctx->stream));
+                ctx->we_calls++;
+            }
+            return r;
         };
         auto launch_vert = [&](hipStream_t st) -> int {
             if (!vert3) return rsgm_launch_vert(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, gst, gmin);
@@ -550,14 +678,16 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             }
             // event pairs around the fused launch: what bench.py prices as the dominant kernel
             const bool timed = !ctx->capturing && st == ctx->stream;
-            if (timed && !ctx->agg_ev_created) {
-                for (int j = 0; j < 2; j++)
-                    for (int i = 0; i < vppx_ctx::AGG_RING; i++) VPPX_HIP(hipEventCreate(&ctx->agg_ev[j][i]));
-                ctx->agg_ev_created = true;
-            }
+            if (timed && (rc = agg_events_create(ctx))) return rc;
             const int slot = (int)(ctx->agg_calls % vppx_ctx::AGG_RING);
             if (timed) VPPX_HIP(hipEventRecord(ctx->agg_ev[0][slot], st));
-            const int r = rsgm_launch_vert3(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err);
+            unsigned *err_dev;
+            {
+                const bool fresh = ctx->ws[WS_V3ERR].p == nullptr;
+                if ((rc = ws_get(ctx, WS_V3ERR, (size_t)4, &err_dev))) return rc;
+                if (fresh) VPPX_HIP(hipMemsetAsync(err_dev, 0, 16, st));
+            }
+            const int r = rsgm_launch_vert3(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev);
             if (timed) {
                 VPPX_HIP(hipEventRecord(ctx->agg_ev[1][slot], st));
                 ctx->agg_calls++;
@@ -565,9 +695,29 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             return r;
         };
         if (which == 0 && vert3) {
-            // one after the other: both launches fill the chip, two streams only interleave them (measured: no gain)
-            if ((rc = launch_we())) return rc;
-            if ((rc = launch_vert(ctx->stream))) return rc;
+            // One after the other: both launches fill the chip, two streams only interleave them (measured: no gain).
+            // Whichever launch follows the front stage finds the gray / census images cold (written by another launch; the
+            // first reader fetches them from HBM, later ones hit the memory-side cache) and its chains wait at every new
+            // line.  The W/E launch pays 0.5-0.65 ms for going first (2.4-2.6 ms instead of 1.95 back to back;
+            // tools/we_probe.py), the fused vertical kernel 0.2-0.3 ms: it goes first (round 4: bench step 9.66 -> 9.45 ms
+            // on the same box).  Reading the images once in a launch of its own has the same effect (VPPX_EXP_PRE=1 of an
+            // EXP=1 build).  (Also tried in round 4, bit-exact, not kept: the vertical kernel adding W's and E's bytes to
+            // its two sums -- 3 whole-line loads per lane and row, prefetched a row ahead -- so that the sum kernel reads
+            // two volumes: sum / WTA 2.46 -> 2.09 ms, but the lock-step kernel 3.5 -> 4.55 ms whatever the loads'
+            // distance, cache policy or target (in place or not): HBM-latency loads in its CUs' miss queues hold up the
+            // L2-hit operand loads every row depends on.)
+#ifdef VPPX_EXPERIMENT
+            const bool we_first = exp_env("VPPX_EXP_ORDER") != 0; // the order of rounds 2-3
+#else
+            const bool we_first = false;
+#endif
+            if (we_first) {
+                if ((rc = launch_we())) return rc;
+                if ((rc = launch_vert(ctx->stream))) return rc;
+            } else {
+                if ((rc = launch_vert(ctx->stream))) return rc;
+                if ((rc = launch_we())) return rc;
+            }
         } else if (which == 0) {
             VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
             VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -591,11 +741,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         nvol = 4;
     } else {
         if ((rc = ws_reserve(ctx, WS_PATHS, ncell * 8 * elem_bytes, &paths))) return rc;
-        if (!ctx->agg_ev_created) {
-            for (int j = 0; j < 2; j++)
-                for (int i = 0; i < vppx_ctx::AGG_RING; i++) VPPX_HIP(hipEventCreate(&ctx->agg_ev[j][i]));
-            ctx->agg_ev_created = true;
-        }
+        if ((rc = agg_events_create(ctx))) return rc;
         if (ctx->capturing) { // event records stay out of a captured graph
             if ((rc = rsgm_launch_paths(ctx, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, nullptr, lut_d, p.p1, paths, elem_bytes, 0xFF))) return rc;
         } else {
@@ -771,6 +917,10 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if ((rc = ws_get(ctx, WS_LABEL, np, &label))) return rc;
     if ((rc = ws_get(ctx, WS_LCOUNT, np, &lcount))) return rc;
     if ((rc = rsgm_launch_post(ctx, g, dl0, dr0, fdscr, fdc, fd8, label, lcount, p.subpixel, disp_out))) return rc;
+    // fused layout: should this call's lock-step launch have given up, its output becomes NaN before anything queued
+    // behind the call can read it (the host learns of it through vppx_status / vppx_synchronize / the next call)
+    if (ctx->last_vert == 3 && ctx->ws[WS_V3ERR].p &&
+        (rc = rsgm_launch_void_if_lost(ctx, disp_out, np, (const unsigned *)ctx->ws[WS_V3ERR].p, ctx->v3.serial))) return rc;
     stage_mark(ctx, ST_POST);
     return 0;
 }
@@ -841,12 +991,17 @@ extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int
         if ((rc = upload(ctx, WS_STAGE_F, validhints, (size_t)B * H * W * sizeof(float), &dv))) return rc;
     }
     for (int attempt = 0;; attempt++) {
+        const unsigned serial_before = ctx->v3.serial; // fused launches up to here belong to earlier (asynchronous) calls
         if ((rc = vppx_rsgm_dev(ctx, p, B, H, W, C, (const u8 *)dl, (const u8 *)dlv, (const u8 *)drv, (const float *)dh, (const float *)dv, (float *)dout))) return rc;
         if ((rc = download(ctx, disp_out, dout, (size_t)B * H * W * sizeof(float)))) return rc;
         VPPX_HIP(hipStreamSynchronize(ctx->stream));
-        // a synchronous entry point knows whether ITS aggregation lost the lock step: run it again on the line-parallel
-        // kernel (the context has just moved there) instead of returning void disparities
-        if (lockstep_check(ctx) == 0 || attempt > 0) break;
+        // A synchronous entry point knows whether ITS aggregation lost the lock step: it runs again on the line-parallel
+        // kernel (the context has just moved there) instead of returning void disparities.  A mark left by an EARLIER
+        // asynchronous fused call is not this call's to swallow: it is reported (once, VPPX_E_HIP), as the header says.
+        if ((rc = lockstep_check(ctx)) == 0) break;
+        const unsigned s = ctx->lockstep_last_serial;
+        const bool mine = (unsigned)(s - serial_before - 1u) < (unsigned)(ctx->v3.serial - serial_before); // serial_before < s <= now (mod 2^32)
+        if (!mine || attempt > 0) return rc;
     }
     return 0;
 }
@@ -1590,6 +1745,30 @@ extern "C" int vppx_agg_kernel_ms(vppx_ctx *ctx, int last_n, float *avg_ms, int 
     }
     *avg_ms = n > 0 ? (float)(tot / (double)n) : 0.f;
     if (n_used) *n_used = (int)n;
+    return 0;
+}
+// The same for the W/E launch of the fused layout (0 launches in the 8-path layout, whose one launch is the one above).
+extern "C" int vppx_we_kernel_ms(vppx_ctx *ctx, int last_n, float *avg_ms, int *n_used)
+{
+    int rc;
+    VPPX_ENTER(ctx);
+    VPPX_PIPE_KEEP(ctx);
+    if (ctx->nsub > 1 && ctx->sub[0]) ctx = ctx->sub[0];
+    if (last_n <= 0) { ctx->we_calls = 0; if (n_used) *n_used = 0; if (avg_ms) *avg_ms = 0.f; return 0; }
+    if (!avg_ms) return VPPX_E_INVALID_ARG;
+    long n = ctx->we_calls < last_n ? ctx->we_calls : last_n;
+    if (n > vppx_ctx::AGG_RING) n = vppx_ctx::AGG_RING;
+    double tot = 0.0;
+    for (long i = 0; i < n; i++) {
+        const int slot = (int)((ctx->we_calls - 1 - i) % vppx_ctx::AGG_RING);
+        float t = 0.f;
+        VPPX_HIP(hipEventSynchronize(ctx->we_ev[1][slot]));
+        VPPX_HIP(hipEventElapsedTime(&t, ctx->we_ev[0][slot], ctx->we_ev[1][slot]));
+        tot += t;
+    }
+    *avg_ms = n > 0 ? (float)(tot / (double)n) : 0.f;
+    if (n_used) *n_used = (int)n;
+    (void)rc;
     return 0;
 }
 // frames per launch that vppx_time_aggregate re-runs (a split batch is timed on one part)

@@ -72,6 +72,7 @@ enum WsSlot {
     WS_SV,           // per-pass sums of the vertical/diagonal paths (band-marching kernel)
     WS_VSTATE,
     WS_VMIN,
+    WS_V3ERR,        // device-side copy of the fused kernel's error word (void_if_lost_kernel)
     WS_DSI,          // materialised cost volume (stage API only)
     WS_DISP_L0,
     WS_DISP_L1,
@@ -142,6 +143,7 @@ struct vppx_ctx {
     bool vert3_broken = false;     // set once vert3_err was seen (or the XCD probe failed): the context stays on the line-parallel kernel
     bool vert3_probed = false;     // rsgm_vert3_probe has run on this context's device
     long lockstep_failures = 0;    // fused launches that reported a lost lock step (vppx_lockstep_failures)
+    unsigned lockstep_last_serial = 0; // serial of the launch the last report was about
     struct V3Caps {                // what rsgm_vert3_probe found out about the device and this build of the kernels
         bool ok = false;
         int nxcd = 0, cus_per_xcd = 0;
@@ -153,7 +155,7 @@ struct vppx_ctx {
         unsigned spin_limit = 0;   // polls per wait, 0 = unbounded (VPPX_V3_SPIN_LIMIT: tests force the give-up path with 1)
         unsigned serial = 0;       // serial of the last fused launch
         int last_ppw = 0;          // pixels per wave of the last fused launch (8: sgm_vert3_kernel, 16: sgm_vert4_kernel)
-        bool ignore_lost = false;  // VPPX_V3_IGNORE_LOST: measurement runs with forced give-ups (results void) carry on
+        bool ignore_lost = false;  // VPPX_V3_IGNORE_LOST (EXP=1 builds only): measurement runs with forced give-ups (results void) carry on
     } v3;
     DevBuf ws[WS_NUM];
     std::string devname;
@@ -170,6 +172,10 @@ struct vppx_ctx {
     hipEvent_t agg_ev[2][AGG_RING];
     bool agg_ev_created = false;
     long agg_calls = 0;
+    // the same around the W/E launch of the fused layout (vppx_we_kernel_ms): its in-step duration differs from what a
+    // back-to-back re-launch measures, so both are on record
+    hipEvent_t we_ev[2][AGG_RING];
+    long we_calls = 0;
     // P2 look-up table: host copy kept alive for the asynchronous upload, re-sent only when the penalties change
     u16 lut_host[256];
     bool lut_valid = false;
@@ -263,7 +269,8 @@ int rsgm_vert3_frames_per_round(const vppx_ctx *ctx, int Wp, int D);
 bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
-                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err);
+                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev);
+int rsgm_launch_void_if_lost(vppx_ctx *ctx, float *out, size_t n, const unsigned *err_dev, unsigned serial);
 bool rsgm_vert_supported(int D, int maxp2);
 size_t rsgm_vert_state_bytes(int B, int Wp, int D);
 size_t rsgm_vert_min_elems(int B, int Wp);

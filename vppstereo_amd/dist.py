@@ -47,17 +47,25 @@ class GatherHandle:
         return full.to(self._staged) if self._staged is not None else full
 
 
-def gather_disparities_async(local_disp, n_frames, dst=0, group=None):
+def gather_disparities_async(local_disp, n_frames, dst=0, group=None, force_collective=False):
     """Start gathering the per-rank [b_local,H,W] float32 disparity shards to rank `dst`.
 
     A gather TO THE ROOT (grouped send/recv under RCCL): only `dst` receives, one shard per xGMI link
     in parallel, nothing travels between the other ranks -- unlike a ring all_gather, whose per-link
     traffic grows with the world size.  Asynchronous: the collective runs on the communicator's own
     stream, so the next batch's kernels overlap it; `local_disp` must stay untouched until `wait()`
-    (double-buffer the output).  Shards are padded to equal size (frame counts differ by at most one)."""
+    (double-buffer the output).  Shards are padded to equal size (frame counts differ by at most one).
+
+    A world of one rank needs no exchange and returns at once -- unless `force_collective` is set, which sends even that
+    case through `torch.distributed.gather` (the communicator is created, the collective is queued on its stream, the
+    caller waits on the work handle): how a one-GPU box exercises the RCCL branch (tests/test_gpu_nccl.py).
+
+    The shards are whatever `Engine.vpp_rsgm` left in `local_disp`; a fused aggregation launch that lost its lock step
+    has turned them into NaN by then (void_if_lost_kernel), so a void shard cannot pass for disparities on the root."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    have_pg = dist.is_available() and dist.is_initialized()
+    if not have_pg or (dist.get_world_size(group) == 1 and not force_collective):
         return GatherHandle(None, [local_disp], local_disp.shape[0], 1, True)
     ws = dist.get_world_size(group)
     rank = dist.get_rank(group)

@@ -317,6 +317,12 @@ class Engine:
         _lib.check(self.lib.vppx_agg_kernel_ms(self.ctx.handle, int(last_n), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def we_kernel_ms(self, last_n):
+        """The same for the W/E launch of the fused layout (0 launches in the 8-path layout)."""
+        ms, n = C.c_float(0), C.c_int(0)
+        _lib.check(self.lib.vppx_we_kernel_ms(self.ctx.handle, int(last_n), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def time_aggregate_frames(self):
         return int(self.lib.vppx_time_aggregate_frames(self.ctx.handle))
 
