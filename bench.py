@@ -43,11 +43,12 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 AGG_BYTES_PER_CELL = 10.0        # aggregation share of the 16 B/cell algorithmic bytes
 PATH_BYTES_PER_CELL = 16.0       # whole path, + 50 B/pixel
 PATH_BYTES_PER_PIXEL = 50.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
-# average issue cost of one VALU wave-instruction of the fused aggregation kernel's row loop: its mix of full-rate (~2.5
-# cycles) and half-rate (~4 cycles: VOP3P, three-operand VOP3, v_bcnt, DPP) instructions priced with the rates
-# tools/valu_bench.hip measured on gfx950 (profiles/r02_valu_issue_rates.txt)
+# average issue cost of one VALU wave-instruction of the FUSED VERTICAL kernel's row loop (and of no other kernel: it is only
+# applied to the dominant kernel's own instruction count): its mix of full-rate (~2.5 cycles) and half-rate (~4 cycles:
+# VOP3P, three-operand VOP3, v_bcnt, DPP) instructions priced with the rates tools/valu_bench.hip measured on gfx950
+# (profiles/r02_valu_issue_rates.txt)
 VALU_CYCLES_PER_INST = 3.3
 
 
@@ -210,22 +211,36 @@ def cpu_baseline(n_frames, gpu_out=None):
     base = dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port",
                 sample=f"{n_frames} full {H}x{W}x{D} frames (occlusion heuristic + VPP rnd + rSGM), oracle/liboracle.so "
                        f"gcc {_oracle_flags().split(' -fPIC')[0]}, 1 thread, {t_tot / n_frames:.2f} s/frame, "
-                       f"host has {os.cpu_count()} cpus")
+                       f"host has {os.cpu_count()} cpus; the port's rSGM is scalar C, about an order of magnitude slower than the "
+                       "SSE rSGM of the literature (SURVEY section 6): the GPU/CPU ratio is not a kernel-quality figure")
     return base, epe
 
 
-def cpu_baseline_parallel(max_procs=16):
-    """Same port, one frame per process over the host cores (bounded: one frame each, <= 16 processes)."""
+def cpu_baseline_parallel():
+    """Same port, one frame per process on every physical core of the host (bounded by memory: a process holds the
+    oracle's cost and path volumes, ~0.5 GB)."""
     import multiprocessing as mp
-    n = max(1, min(max_procs, (os.cpu_count() or 1)))
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or logical
+        mem_procs = int(psutil.virtual_memory().available / (0.75 * 2 ** 30))
+    except Exception:  # noqa: BLE001
+        phys, mem_procs = logical, logical
+    try:
+        phys = min(phys, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    n = max(1, min(phys, mem_procs))
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(n) as pool:
-        per = pool.map(_cpu_worker, list(range(n)))
+        per = pool.map(_cpu_worker, list(range(n)), chunksize=1)
     wall = time.perf_counter() - t0
     return dict(value=n * H * W * D / wall / 1e6, unit="Mdisparities/s", cores=n, kind="port",
-                sample=f"{n} frames on {n} processes, wall {wall:.1f} s (includes frame synthesis), "
-                       f"mean {sum(per) / n:.2f} s/frame/core")
+                sample=f"{n} frames on {n} processes = the host's physical cores ({logical} logical cpus; memory allows {mem_procs} "
+                       f"processes), wall {wall:.1f} s (includes frame synthesis), mean {sum(per) / n:.2f} s/frame/core; the port's "
+                       "rSGM is scalar C (about an order of magnitude slower than the SSE rSGM of the literature, SURVEY section 6)")
 
 
 def kernel_source_sha():
@@ -316,13 +331,17 @@ def pmc_view(agg_frames, kernel_ms, kernel="sgm_paths_kernel"):
     return out
 
 
-def other_config(eng, torch, synth, name, h, w, d, p, batch, steps=4, warmup=2):
+def other_config(eng, torch, synth, name, h, w, d, p, batch, steps=4, warmup=2, tensors=None):
     """One of the other BASELINE.json configurations, same loop as the headline (mask, overlap, inputs resident), bounded:
-    `batch` distinct synthetic scenes, a few steps.  Parity at these sizes: tests/test_gpu_fullsize.py, test_gpu_headline.py."""
+    `batch` distinct synthetic scenes, a few steps.  Parity at these sizes: tests/test_gpu_fullsize.py, test_gpu_headline.py.
+    `tensors`: resident (left, right, hints) to take the first `batch` frames of instead of synthesising new scenes."""
     import numpy as np
     dev = eng.device
-    b = synth.make_batch(batch, h, w, d, p, seed=4321)
-    left, right, hints = (torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints"))
+    if tensors is not None:
+        left, right, hints = (t[:batch].contiguous() for t in tensors)
+    else:
+        b = synth.make_batch(batch, h, w, d, p, seed=4321)
+        left, right, hints = (torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints"))
     occ = torch.empty((batch, h, w), dtype=torch.uint8, device=dev)
     outs = [torch.empty((batch, h, w), dtype=torch.float32, device=dev) for _ in range(2)]
     torch.cuda.synchronize()
@@ -592,15 +611,13 @@ def run_rank(args):
                                                                  pmc.get("sq_wait_any_frac_of_wave_cycles")]}
         dom = {"kernel": (f"{dom_kernel} (N, NW, NE and S, SW, SE fused three at a time: 6 of the 8 aggregation paths; "
                           f"{16 if wide else 8} pixels per wave)" if fused else "sgm_paths_kernel (8-path aggregation)"),
-               "bound": "valu",
+               "limited_by": "valu issue",
                "kernel_ms": round(agg_ms, 4), "kernel_launches_timed": agg_n, "kernel_ms_back_to_back": round(agg_ms_b2b, 4),
                "share_of_step": round(agg_ms / ms_per_step, 3),
                "valu": valu,
-               "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None,
                "traffic_unit": "GB per launch (PMC)",
                "hbm_frac_of_peak": pmc.get("hbm_frac_of_peak") if pmc else None,
-               "convention_frac": round(achieved / HBM_PEAK_GBS, 4),
-               "convention": f"{agg_bytes} B/cell = SURVEY 8d's 10 B/cell of the 8-path aggregation, pro rata for the paths this launch "
+               "algorithmic_bytes": f"{agg_bytes} B/cell = SURVEY 8d's 10 B/cell of the 8-path aggregation, pro rata for the paths this launch "
                              f"carries: {round(cells_launch * agg_bytes / 1e9, 3)} GB per launch / kernel_ms vs 8 TB/s (a byte-count "
                              "convention, not a utilisation: see valu and hbm_frac_of_peak)",
                "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": {"in_step": round(we_ms_in_step, 4) if we_n else None,
@@ -628,22 +645,24 @@ def run_rank(args):
             "ranks": {"launched": args.gpus, "seen": dist.get_world_size() if world > 1 else 1,
                       "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
                       "ms_per_step_per_rank": [round(x, 3) for x in rank_ms]},
-            # SURVEY 8d's roofline of this path: Mdisp/s x (16 B per cell + 50 B per pixel) against the HBM peak.  This is the
-            # figure north_star's ">= 60 %" is about; it prices the REFERENCE's dataflow, the build moves less (traffic).
-            "roofline": {"bound": "hbm",
-                         "what": "whole step at SURVEY 8d's algorithmic bytes, H*W*(16*D + 50) B per frame, vs the HBM3E peak",
-                         "achieved": round(pipeline_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
-                         "frac_unpipelined": (round(pipeline_gbs * ms_per_step / ms_unpipelined / HBM_PEAK_GBS, 4) if ms_unpipelined else None),
-                         "algorithmic_GB_per_step": round(n_total / world * H * W * (PATH_BYTES_PER_CELL * D + PATH_BYTES_PER_PIXEL) / 1e9, 3),
-                         "traffic": step_traffic,
-                         "traffic_unit": "GB of real HBM traffic per step and GPU, all kernels (PMC FETCH_SIZE x2 + WRITE_SIZE, separate "
-                                         "rocprofv3 passes; null unless the committed profile was taken from these kernel sources)",
-                         "hbm_frac_of_peak": (round(step_traffic / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4) if step_traffic else None),
-                         "dominant_kernel": dom},
-            "pipeline_roofline": {"bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,
-                                  "achieved_GBps": round(pipeline_gbs, 1), "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
-                                  "note": "same figure as roofline (kept under its round-2 name)"},
+            # The dominant kernel (bench contract): SURVEY 8d's algorithmic bytes of the launch -- 10 B/cell for the 8-path
+            # aggregation, pro rata for the paths the launch carries -- over its average duration inside the timed steps
+            # (hipEvent pairs on the launch stream), against the HBM3E peak; `traffic` = the launch's real HBM bytes (PMC).
+            # It is a byte-count convention: the kernel is bound by instruction issue (`valu`), `hbm_frac_of_peak` is its
+            # utilisation.  The whole step against the same peak (north_star's ">= 60 %") is `pipeline_roofline`.
+            "roofline": dict({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4),
+                              "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None}, **dom),
+            "pipeline_roofline": {"what": "whole step at SURVEY 8d's algorithmic bytes, H*W*(16*D + 50) B per frame, vs the HBM3E peak "
+                                          "(the figure north_star's 60 % is about; it prices the REFERENCE's dataflow, the build moves less: traffic)",
+                                  "bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,
+                                  "achieved_GBps": round(pipeline_gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
+                                  "frac_unpipelined": (round(pipeline_gbs * ms_per_step / ms_unpipelined / HBM_PEAK_GBS, 4) if ms_unpipelined else None),
+                                  "algorithmic_GB_per_step": round(n_total / world * H * W * (PATH_BYTES_PER_CELL * D + PATH_BYTES_PER_PIXEL) / 1e9, 3),
+                                  "traffic": step_traffic,
+                                  "traffic_unit": "GB of real HBM traffic per step and GPU, all kernels (PMC FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                                  "rocprofv3 passes; null unless the committed profile was taken from these kernel sources)",
+                                  "hbm_frac_of_peak": (round(step_traffic / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4) if step_traffic else None)},
             ("ms_per_step_without_g_occ" if use_occ else "ms_per_step_with_g_occ"): other,
             "b1": {"ms_per_frame": round(b1_ms, 4), "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),
                    "what": "one frame per call (B=1), host-paced loop of 20 calls, same stages as the step"
@@ -668,17 +687,38 @@ def run_rank(args):
         if world == 1 and not args.no_other_configs and not args.shape and not args.uniform_random and not args.graph:
             # the other BASELINE.json configurations on this one GPU (their multi-GPU form shards frames: section 7 of DESIGN.md)
             q3 = eng.batch_quantum(375, 1242, 192)
-            cfg3_b = 3 * q3 if 0 < q3 <= 16 else 32
+            cfg3_q = 3 * q3 if 0 < q3 <= 16 else 0
             result["config"]["batch_quantum"] = {"540x960x192": eng.batch_quantum(H, W, D), "375x1242x192": q3, "1536x2048x256": eng.batch_quantum(1536, 2048, 256)}
-            result["other_configs"] = [
-                # frames per step = three batch quanta of this width (vppx_batch_quantum: 12 on an MI355X -> 36 frames; the
-                # 32 of rounds 1-2 left the third round of the lock-step kernel two-thirds full)
-                other_config(eng, torch, synth, "cfg3: KITTI-sized 375x1242 stream, 5%% hints, D=192, %d frames per step" % cfg3_b, 375, 1242, 192, 0.05, cfg3_b),
+            b3 = synth.make_batch(max(32, cfg3_q), 375, 1242, 192, 0.05, seed=4321)
+            t3 = tuple(torch.from_numpy(np.ascontiguousarray(b3[k])).to(dev) for k in ("left", "right", "hints"))
+            cfg3 = [other_config(eng, torch, synth, "cfg3: KITTI-sized 375x1242 stream, 5% hints, D=192, 16 frames per step (BASELINE's 32 frames "
+                                 "over 2 GPUs: the per-GPU batch)", 375, 1242, 192, 0.05, 16, tensors=t3),
+                    other_config(eng, torch, synth, "cfg3: the same stream, 32 frames per step on one GPU", 375, 1242, 192, 0.05, 32, tensors=t3)]
+            if cfg3_q and cfg3_q not in (16, 32):
+                # frames per step = three batch quanta of this width (vppx_batch_quantum: whole rounds of the lock-step kernel)
+                cfg3.append(other_config(eng, torch, synth, "cfg3: the same stream, %d frames per step (three batch quanta of this width)" % cfg3_q,
+                                         375, 1242, 192, 0.05, cfg3_q, tensors=t3))
+            del t3, b3
+            result["other_configs"] = cfg3 + [
                 other_config(eng, torch, synth, "cfg5: 1536x2048 indoor pairs, 1% hints, D=256, 8 frames per step", 1536, 2048, 256, 0.01, 8, steps=3, warmup=1),
                 {"config": "cfg2 literal: one 540x960 pair per call, D=192", "ms_per_frame": round(b1_ms, 4),
                  "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),
                  "roofline_frac": round(H * W * D / b1_ms / 1e3 * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / D) / 1e9 / HBM_PEAK_GBS, 4)},
             ]
+            # latency / throughput curve of the headline shape: frames per call from the reference's operating point (one pair,
+            # test.py:293) to the headline batch, same loop (mask, overlap, inputs resident), the first b frames of the batch
+            sweep = []
+            for bsz in (1, 2, 4, 8, 16):
+                if bsz >= B:
+                    break
+                r = other_config(eng, torch, synth, f"{bsz} frames per call", H, W, D, P_HINTS, bsz, steps=max(4, min(24, 64 // bsz)), warmup=3,
+                                 tensors=(left, right, hints))
+                sweep.append({"frames_per_call": bsz, "ms_per_call": r["ms_per_step"], "ms_per_frame": round(r["ms_per_step"] / bsz, 4),
+                              "Mdisparities_per_s": r["Mdisparities_per_s"], "roofline_frac": r["roofline_frac"],
+                              "aggregation_layout": r["aggregation_layout"]})
+            sweep.append({"frames_per_call": B, "ms_per_call": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step / B, 4),
+                          "Mdisparities_per_s": round(value, 1), "roofline_frac": round(pipeline_gbs / HBM_PEAK_GBS, 4), "aggregation_layout": layout})
+            result["batch_sweep"] = sweep
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

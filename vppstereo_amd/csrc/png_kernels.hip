@@ -605,7 +605,14 @@ int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const lon
     const size_t lds = PNG_IN_SZ + PNG_RING + 2 * PNG_ROWMAX + ((1 << PNG_LBITS) + (1 << PNG_DBITS)) * 2 + 32 + 576 + 32 + 64 + 384;
     static bool attr_set[VPPX_MAX_DEVICES] = {};
     if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)]) {
-        VPPX_HIP(hipFuncSetAttribute((const void *)png_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // the decoder keeps the LZ77 window, two scanlines and its tables in LDS (~110 KB per file): say so where that does
+        // not fit a workgroup instead of failing with a generic HIP error (the library only runs on gfx950, which has 160 KB)
+        if (hipFuncSetAttribute((const void *)png_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            vppx_set_error("device PNG decoder needs %zu bytes of LDS per workgroup, which this device does not offer: decode on the "
+                           "host and upload the samples (vppx_kitti_disp_decode_dev)", lds);
+            return VPPX_E_UNSUPPORTED;
+        }
         attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)] = true;
     }
     png_decode_kernel<<<dim3(n_files), 64, lds, ctx->stream>>>(j);
