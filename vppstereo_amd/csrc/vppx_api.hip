@@ -480,6 +480,32 @@ static int check_rsgm_params(const VppxRsgmParams &p)
 // 8-path aggregation stage.  which: 0 = everything, 1 = horizontal paths only, 2 = vertical bands
 // only (timing helpers).  Fills vols[] with the volumes the sum/WTA kernel has to add.
 // ---------------------------------------------------------------------------------------
+// Would a call of this geometry take the fused layout (W/E line-parallel + the lock-step vertical kernel)?  use_vert: -1
+// (default) = pick by shape, 0 = eight line-parallel paths, 3 = fused whenever the shape allows it.  Probes the device on
+// the first question (block placement, residency).
+static int fused_layout_wanted(vppx_ctx *ctx, const RsgmGeom &g, int maxp2, bool *out)
+{
+    int rc;
+    *out = false;
+    const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
+    bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
+    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
+        // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes
+        // (8 XCDs, round-robin), and how many blocks of this build of the kernel does one XCD hold?
+        if ((rc = v3_probe_once(ctx))) return rc;
+    }
+    if (!ctx->vert3_probed) v3_ok = false; // (e.g. a first call inside a graph capture takes the 8-path layout)
+    v3_ok = v3_ok && !ctx->vert3_broken && rsgm_vert3_fits(ctx, g.B, g.Wp, g.D); // a whole group + early arrivals resident per XCD
+    // (measured at B=32, 8-path / fused ms per step: D=64 7.5 / 7.5, D=128 10.6 / 9.2, D=192 13.3 / 11.7; 1536x2048x256 at
+    // B=8 28.1 / 28.9: the default takes the fused layout for D = 128 and 192)
+    // Default: the fused layout from 8 frames per launch on for D = 128 / 192, and for every D once the batch fills the chip
+    // with groups of the 16-pixels-per-wave kernel (round 3, ms per step 8-path / fused 8 px per wave / fused 16 px per wave:
+    // 540x960 B=32 D=64 7.4 / 7.5 / 6.8, D=128 10.6 / 9.3 / 9.0; 375x1242x192 B=32 12.1 / 10.4 / 10.2; 1536x2048x256 B=8
+    // 28.7 / 32.0 / 23.1, B=16 56.4 / 64.4 / 46.1)
+    *out = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192 || rsgm_vert3_wide(ctx, g.B, g.Wp, g.D))));
+    return 0;
+}
+
 #ifdef VPPX_EXPERIMENT
 // Experiment hooks (never in the shipped build; `make EXP=1`): what runs right before the W/E launch of a step.
 //   VPPX_EXP_PRE=1  read every census / gray byte the launch will read (warms L2 / MALL / TLB of those)
@@ -616,21 +642,8 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     // (round-1 experiment), 3 = fused vertical kernel whenever the shape allows it.  The fused kernel wins from 8 frames
     // per launch on (540x960x192, ms per step 8-path / fused: B=4 2.20 / 2.26, B=8 3.74 / 3.27, B=16 6.94 / 5.90,
     // B=32 13.3 / 11.7); a context whose fused launch once lost its lock step never uses it again.
-    bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
-    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
-        // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes
-        // (8 XCDs, round-robin), and how many blocks of this build of the kernel does one XCD hold?
-        if ((rc = v3_probe_once(ctx))) return rc;
-    }
-    if (!ctx->vert3_probed) v3_ok = false; // (e.g. a first call inside a graph capture takes the 8-path layout)
-    v3_ok = v3_ok && !ctx->vert3_broken && rsgm_vert3_fits(ctx, g.B, g.Wp, g.D); // a whole group + early arrivals resident per XCD
-    // (measured at B=32, 8-path / fused ms per step: D=64 7.5 / 7.5, D=128 10.6 / 9.2, D=192 13.3 / 11.7; 1536x2048x256 at
-    // B=8 28.1 / 28.9: the default takes the fused layout for D = 128 and 192)
-    // Default: the fused layout from 8 frames per launch on for D = 128 / 192, and for every D once the batch fills the chip
-    // with groups of the 16-pixels-per-wave kernel (round 3, ms per step 8-path / fused 8 px per wave / fused 16 px per wave:
-    // 540x960 B=32 D=64 7.4 / 7.5 / 6.8, D=128 10.6 / 9.3 / 9.0; 375x1242x192 B=32 12.1 / 10.4 / 10.2; 1536x2048x256 B=8
-    // 28.7 / 32.0 / 23.1, B=16 56.4 / 64.4 / 46.1)
-    const bool vert3 = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192 || rsgm_vert3_wide(ctx, g.B, g.Wp, g.D))));
+    bool vert3;
+    if ((rc = fused_layout_wanted(ctx, g, maxp2, &vert3))) return rc;
     const bool vert = vert3 || (ctx->use_vert == 1 && elem_bytes == 1 && rsgm_vert_supported(g.D, maxp2) && g.D <= 192);
     ctx->last_vert = vert3 ? 3 : (vert ? 1 : 0);
     void *paths;
@@ -1251,6 +1264,63 @@ extern "C" int vppx_occ_vpp_rsgm_dev(vppx_ctx *ctx, const VppxOccParams *op, con
     return rc;
 }
 
+// Batches larger than one round of the lock-step kernel are run as consecutive parts of one round each ("batch quantum":
+// 16 frames at 540x960x192, 12 at 375x1242x192).  Frames are independent and frame f draws from srand(seed + f) whatever
+// the split, so results do not change; what changes is the length of the bursts: 32 frames per launch keep the chip's
+// hottest kernel running for 3.5 ms, and it clocks down under its power limit (tools/clock_trace.py: 2.25 -> 2.05 GHz
+// inside a step; the kernel takes 3.55 ms inside a step against 3.30 re-launched alone), while 16-frame parts alternate
+// 1.65 ms of it with the cooler W/E, sum and post launches (bench at 540x960x192, ms per frame: 16 per call 0.285, 32 per
+// call 0.294, 48: 0.290, 24: 0.317 -- 1.5 rounds).  The part in front takes the remainder (or, below 8 frames, rides on
+// the first full part) so that the last part -- the one the timing helpers re-launch -- is a whole round.  With
+// vppx_set_pipeline the front stage of a part runs under the previous part's sum / WTA and post kernels, as between calls.
+// VPPX_CHUNK=0 keeps whole batches, VPPX_CHUNK=n forces parts of n frames.
+static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
+                          int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                          uint8_t *conf_out, uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
+{
+    int rc;
+    static const int chunk_env = getenv("VPPX_CHUNK") ? atoi(getenv("VPPX_CHUNK")) : -1;
+    int q = 0;
+    if (chunk_env > 0) {
+        q = chunk_env;
+    } else if (chunk_env < 0 && !ctx->stage_timing && !ctx->is_child && B >= 16) {
+        RsgmGeom g1;
+        make_geom(1, H, W, C, rp->dmax, g1);
+        u16 lut[256];
+        int maxp2 = 0;
+        p2_lut_host(*rp, lut, &maxp2);
+        if (!ctx->vert3_broken && (ctx->vert3_probed || !ctx->capturing) && v3_probe_once(ctx) == 0 && !ctx->vert3_broken) {
+            const int fpr = rsgm_vert3_frames_per_round(ctx, g1.Wp, g1.D);
+            bool fused = false;
+            if (fpr >= 8 && fpr < B) {
+                g1.B = fpr;
+                if ((rc = fused_layout_wanted(ctx, g1, maxp2, &fused))) return rc;
+            }
+            if (fused) q = fpr;
+        }
+    }
+    if (q <= 0 || q >= B) return vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
+    const size_t fpx = (size_t)H * W;
+    void *const inputs_ev = ctx->inputs_ev; // one-shot per CALL: every part's front stage may start on it
+    int lo = 0;
+    while (lo < B) {
+        int nb = (B - lo) % q;
+        if (nb == 0) nb = q;
+        else if (nb < 8 && B - lo > q) nb += q; // a few frames do not make a launch of their own
+        VppxVppParams v2 = *vp;
+        v2.seed = vp->seed + (uint32_t)lo; // frame f keeps srand(seed + f) whatever the split
+        ctx->inputs_ev = inputs_ev;
+        rc = vpp_rsgm_one(ctx, op, &v2, rp, nb, H, W, C, left + (size_t)lo * fpx * C, right + (size_t)lo * fpx * C,
+                          g + (size_t)lo * fpx, g_occ ? g_occ + (size_t)lo * fpx : nullptr,
+                          conf_out ? conf_out + (size_t)lo * fpx : nullptr,
+                          l_vpp ? l_vpp + (size_t)lo * fpx * C : nullptr, r_vpp ? r_vpp + (size_t)lo * fpx * C : nullptr,
+                          disp_out + (size_t)lo * fpx);
+        if (rc) return rc;
+        lo += nb;
+    }
+    return 0;
+}
+
 static int vpp_rsgm_entry(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
                           int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
                           uint8_t *conf_out, uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
@@ -1290,7 +1360,7 @@ static int vpp_rsgm_entry(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
             hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 ctx->capturing = true;
-                rc = vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
+                rc = vpp_rsgm_parts(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
                 ctx->capturing = false;
                 hipGraph_t graph = nullptr;
                 e = hipStreamEndCapture(ctx->stream, &graph);
@@ -1319,15 +1389,15 @@ static int vpp_rsgm_entry(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
             // capture is not possible here (e.g. the legacy default stream): stay on the eager path
             (void)hipGetLastError();
             ctx->graph_mode = false;
-            return vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
+            return vpp_rsgm_parts(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
         }
-        rc = vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
+        rc = vpp_rsgm_parts(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
         key.ws_gen = ctx->ws_gen; // the workspace as this call left it
         ctx->lastkey = key;
         ctx->have_lastkey = (rc == 0);
         return rc;
     }
-    if (nsub <= 1) return vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
+    if (nsub <= 1) return vpp_rsgm_parts(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
     // Frames are independent: split the batch over child contexts (own stream + arena).  The
     // latency-bound stages of one part (VPP replay, post-processing) then overlap the
     // bandwidth-bound stages of another (aggregation stores, sum/WTA loads).
