@@ -646,17 +646,22 @@ __device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int 
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
 #pragma unroll
     for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? ids[i] : 0xFFFFFFFFu;
-    // scan order = ascending (row, idx in row): sorting network for 8 keys
+    // scan order = ascending (row, idx in row): sorting network for 8 keys (most lists hold one or two hints)
 #define CS(a, b) { const u32 lo_ = min(ids[a], ids[b]), hi_ = max(ids[a], ids[b]); ids[a] = lo_; ids[b] = hi_; }
-    CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
-    CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
+    if (n == 2) {
+        CS(0, 1)
+    } else if (n > 2) {
+        CS(0, 1) CS(2, 3) CS(4, 5) CS(6, 7) CS(0, 2) CS(1, 3) CS(4, 6) CS(5, 7) CS(1, 2) CS(5, 6)
+        CS(0, 4) CS(3, 7) CS(1, 5) CS(2, 6) CS(1, 4) CS(3, 6) CS(2, 4) CS(3, 5) CS(3, 4)
+    }
 #undef CS
-#pragma unroll
-    for (int i = 0; i < RLCAP; i++) {
-        if (i < n) {
-            const int yy = (int)(ids[i] >> 16), hi = (int)(ids[i] & 0xFFFFu);
-            r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], 0x7FFFFFFF);
-        }
+    // (a loop, not eight unrolled copies of the replay: eight copies of the float64 blends of four channels made this kernel
+    // 75 KB of code -- more than the instruction cache two CUs share)
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        const u32 id = i == 0 ? ids[0] : i == 1 ? ids[1] : i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
+        const int yy = (int)(id >> 16), hi = (int)(id & 0xFFFFu);
+        r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], 0x7FFFFFFF);
     }
     for (int j = 0; j < k.C; j++) px[j] = R[j];
 }

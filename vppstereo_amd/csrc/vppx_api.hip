@@ -170,6 +170,8 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         ctx->use_vert = e ? atoi(e) : -1;
         e = getenv("VPPX_GRAPH");
         if (e && atoi(e) > 0) ctx->graph_mode = true;
+        e = getenv("VPPX_PIPE_MID"); // 1: the next front stage starts behind the vertical kernel, next to W/E (measured: 9.16 -> 9.6 ms per step, W/E 0.99 -> 1.15 ms per 16 frames)
+        if (e) ctx->pipe_mid = atoi(e) != 0;
         e = getenv("VPPX_SUBSTREAMS");
         if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
         // bounds of one neighbour wait in the fused aggregation kernel: milliseconds of wall clock (the bound that counts)
@@ -729,6 +731,15 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 if ((rc = launch_vert(ctx->stream))) return rc;
             } else {
                 if ((rc = launch_vert(ctx->stream))) return rc;
+                // VPPX_PIPE_MID=1 (experiment, off): the NEXT call's front stage starts here, next to the W/E launch and the sum / WTA
+                // kernel (it used to start after the whole aggregation).  The lock-step kernel is the one that suffers from
+                // neighbours and it is done; the images W/E still reads belong to this call's set of the two alternating
+                // sets (rsgm_core), which the next front stage does not touch.
+                if (ctx->pipe_call && !ctx->pipe_early && ctx->pipe_mid) {
+                    VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
+                    ctx->have_agg_done = true;
+                    ctx->agg_done_recorded = true;
+                }
                 if ((rc = launch_we())) return rc;
             }
         } else if (which == 0) {
@@ -888,8 +899,9 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     // per-path values are bounded by Cmax + P2max (L_r - min L_r <= P2): bytes suffice when that is < 256
     const void *vols[8];
     int nvol = 0, elem_bytes = 1;
+    ctx->agg_done_recorded = false;
     if ((rc = run_aggregation(ctx, p, g, gl, cl, cr, lut_d, maxp2, vols, &nvol, &elem_bytes, 0, hints, validhints))) return rc;
-    if (ctx->pipe_call && !ctx->pipe_early) { // the next pipelined call's front stage may start now
+    if (ctx->pipe_call && !ctx->pipe_early && !ctx->agg_done_recorded) { // the next pipelined call's front stage may start now
         VPPX_HIP(hipEventRecord(ctx->ev_agg_done, ctx->stream));
         ctx->have_agg_done = true;
     }

@@ -130,6 +130,8 @@ struct vppx_ctx {
     bool have_agg_done = false;
     bool pipe_early = false;       // this pipelined call lets the next front stage start next to its aggregation (few frames per call)
     int pipe_parity = 0;           // which set of gray / census images the next pipelined call writes
+    bool pipe_mid = false;         // the next front stage starts behind the fused vertical kernel, next to W/E (VPPX_PIPE_MID)
+    bool agg_done_recorded = false; // ... and this call's aggregation has recorded ev_agg_done already
     const u8 *last_gl = nullptr;   // the images the last call aggregated from (timing helpers)
     const u32 *last_cl = nullptr, *last_cr = nullptr;
     hipStream_t stream_front = nullptr, main_saved = nullptr;
