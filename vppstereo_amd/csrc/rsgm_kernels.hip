@@ -936,6 +936,215 @@ __global__ void __launch_bounds__(256) sgm_paths_kernel(PathArgs a)
                                                       nsteps, dbase, P1pk, first, last, line_active);
 }
 
+// ---------------------------------------------------------------------------------------
+// W and E of the fused layout at D = 192 (round 4): sgm_paths_kernel<16, 12> with the right-image census window kept in
+// registers.  A lane's 12 disparities need cr[x - dbase - j], j = 0..11: from one step to the next the window moves by ONE
+// word, yet the line kernel reloads all 12 (three unaligned 16-byte loads per lane and step, plus their addressing).  Here
+// the loop is unrolled by 12 -- the window's length -- so that "which register holds cr[x - dbase - j]" is a compile-time
+// rotation (r[(K -+ j) mod 12] at unrolled position K) and a step brings in one new word: an aligned 16-byte load per lane
+// every FOUR steps, eight steps ahead of its use.  The left census word and the gray value of a step come four steps ahead
+// through two 4-entry rings, the volume stores use the instruction's immediate offset inside a 12-step group.  Per step:
+// 3.25 memory instructions instead of 6, no per-step address arithmetic, the cost of d > x (first 191 columns) selected in
+// a wave-uniform branch.  Same arithmetic as sgm_update<.., FUSE, PRE>: bit-identical volumes.
+// Four rows per wave (16 lanes x 12 disparities per pixel), four waves per block; both directions in one launch.
+// ---------------------------------------------------------------------------------------
+struct We12Args {
+    const u8 *gray;
+    const u32 *cl;
+    const u32 *cr;
+    const u16 *p2lut;
+    u8 *out;          // [2][B][Hp][Wp][192]: W, E
+    int Hp, Wp, p1, B;
+    size_t vol_elems;
+};
+
+struct We12State {
+    u32 L[6];
+    u32 minpk;
+    u32 prevI;
+    u32 r[12];    // the window, rotating
+    u32 T[3][4];  // new right-census words of this quad of steps and of the two quads ahead
+    u32 CL[4];    // left census word / gray value of this step and of the three ahead
+    u32 GI[4];
+};
+
+// Addresses are "wave-uniform base + 32-bit lane offset" (scalar-base addressing: the position along the line is uniform,
+// what differs between lanes is the row and the disparity chunk), so a step spends no vector arithmetic on them.
+template <bool EAST>
+__device__ __forceinline__ void we12_load_quad(u32 (&T)[4], const u32 *cr_fm512 /* frame's right census - 512 words */, u32 lane_cr_off,
+                                               int Q, int Wp)
+{
+    typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+    if (!EAST) { // steps x = 4Q .. 4Q+3 bring in cr[x - dbase]
+        const u32x4 v = *(const u32x4 *)((const char *)(cr_fm512 + 4 * Q) + (size_t)lane_cr_off);
+        T[0] = v.x; T[1] = v.y; T[2] = v.z; T[3] = v.w;
+    } else {     // steps x = Wp-1-4Q-i bring in cr[x - dbase - 11]: descending, one word off a 16-byte boundary
+        const u32x4a v = *(const u32x4a *)((const char *)(cr_fm512 + (Wp - 15 - 4 * Q)) + (size_t)lane_cr_off);
+        T[0] = v.w; T[1] = v.z; T[2] = v.y; T[3] = v.x;
+    }
+}
+
+struct We12Lane {
+    const u32 *cr_fm512; // uniform bases of the frame
+    const u32 *cl_f;
+    const u8 *gray_f;
+    u32 cr_off;          // lane offsets in bytes: (row * Wp - dbase + 512) * 4, row * Wp * 4, row * Wp, row * Wp * 192 + dbase
+    u32 cl_off, gray_off, out_off;
+    int dbase;
+};
+
+template <bool EAST, int K>
+__device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const We12Lane &ln, u8 *out_g /* uniform: the group's first pixel */,
+                                          int t0, int Wp, u32 P1pk, bool masked, int nquads)
+{
+    const int t = t0 + K;
+    if (t >= Wp) return; // (wave-uniform: the last group of a line whose length is no multiple of 12)
+    const int x = EAST ? Wp - 1 - t : t;
+    // ---- the step's new right-census word enters the window
+    st.r[EAST ? (K + 11) % 12 : K] = st.T[K / 4][K % 4];
+    const u32 clv = st.CL[K % 4];
+    const u32 I = st.GI[K % 4];
+    // ---- operands of the steps ahead (scalar, clamped positions: t is wave-uniform)
+    {
+        int ta = t + 4;
+        ta = ta < Wp ? ta : Wp - 1;
+        const int xa = EAST ? Wp - 1 - ta : ta;
+        st.CL[K % 4] = *(const u32 *)((const char *)(ln.cl_f + xa) + (size_t)ln.cl_off);
+        st.GI[K % 4] = *((const u8 *)(ln.gray_f + xa) + (size_t)ln.gray_off);
+    }
+    if (K % 4 == 0) {
+        int Q = t / 4 + 2;
+        Q = Q < nquads ? Q : nquads - 1;
+        we12_load_quad<EAST>(st.T[(K / 4 + 2) % 3], ln.cr_fm512, ln.cr_off, Q, Wp);
+    }
+    // ---- matching costs of the lane's 12 disparities: pair i = (dbase + 2i, dbase + 2i + 1)
+    u32 C[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const u32 w0 = st.r[EAST ? (K + 2 * i) % 12 : (K - 2 * i + 24) % 12];
+        const u32 w1 = st.r[EAST ? (K + 2 * i + 1) % 12 : (K - 2 * i - 1 + 24) % 12];
+        const u32 c0 = __popc(clv ^ w0), c1 = __popc(clv ^ w1);
+        C[i] = (c1 << 16) | c0;
+    }
+    if (masked) { // d > x has no right-image pixel: InvalidDispCost.  (A real, wave-uniform branch: the empty asm keeps the
+                  // compiler from turning it into a dozen selects that every step would execute.)
+        const int lim = x - ln.dbase;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const u32 keep = (2 * i <= lim ? 0xFFFFu : 0u) | (2 * i + 1 <= lim ? 0xFFFF0000u : 0u);
+            u32 c = (C[i] & keep) | (~keep & (INVALID_DISP_COST | (INVALID_DISP_COST << 16)));
+            asm volatile("" : "+v"(c));
+            C[i] = c;
+        }
+    }
+    const u32 di = __builtin_amdgcn_sad_u8(I, st.prevI, 0u);
+    const u32 P2pk = s_lut[di];
+    const u32 inact[6] = {0, 0, 0, 0, 0, 0};
+    sgm_update<6, true, 16, true, true>(st.L, C, C, C, P1pk, P2pk, st.minpk, inact, false, false);
+    st.prevI = I;
+    // ---- the pixel's 12 bytes of this lane (values < 256 by construction of the byte variant), streaming store
+    u32 bw[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) bw[i] = __builtin_amdgcn_perm(st.L[2 * i + 1], st.L[2 * i], 0x06040200u);
+    store_words_nt<3>((u32 *)(out_g + (EAST ? -K : K) * 192 + (size_t)ln.out_off), bw);
+}
+
+template <bool EAST>
+__device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, const We12Lane &ln, u8 *out_f /* uniform: frame of this direction's volume */,
+                                          u32 P1pk)
+{
+    const int Wp = a.Wp, nquads = Wp / 4;
+    We12State st;
+#pragma unroll
+    for (int i = 0; i < 6; i++) st.L[i] = 0; // first step: L = 0, min = 0 => L = C
+    st.minpk = 0;
+    {
+        // the window before the first step: W needs cr[-dbase-11 .. -dbase-1] in slots 1..11, E needs cr[Wp-1-dbase-j] in slot j
+        const u32 *p = (const u32 *)((const char *)(ln.cr_fm512 + (EAST ? Wp - 12 : -12)) + (size_t)ln.cr_off);
+        const u32x4 v0 = *(const u32x4 *)p, v1 = *(const u32x4 *)(p + 4), v2 = *(const u32x4 *)(p + 8);
+        const u32 blk[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+        for (int m = 0; m < 12; m++) st.r[m] = EAST ? blk[11 - m] : blk[m];
+    }
+    we12_load_quad<EAST>(st.T[0], ln.cr_fm512, ln.cr_off, 0, Wp);
+    we12_load_quad<EAST>(st.T[1], ln.cr_fm512, ln.cr_off, 1 < nquads ? 1 : 0, Wp);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ta = i < Wp ? i : Wp - 1;
+        const int xa = EAST ? Wp - 1 - ta : ta;
+        st.CL[i] = *(const u32 *)((const char *)(ln.cl_f + xa) + (size_t)ln.cl_off);
+        st.GI[i] = *((const u8 *)(ln.gray_f + xa) + (size_t)ln.gray_off);
+    }
+    st.prevI = st.GI[0];
+    for (int t0 = 0; t0 < Wp; t0 += 12) {
+        // any step of this group in the first 191 columns?  (W: at the start of the line, E: at its end)
+        const bool masked = EAST ? (Wp - 1 - (t0 + 11) < 191) : (t0 < 191);
+        u8 *out_g = out_f + (size_t)(EAST ? Wp - 1 - t0 : t0) * 192;
+        we12_step<EAST, 0>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 1>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 2>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 3>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 4>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 5>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 6>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 7>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 8>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 9>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 10>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 11>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+    }
+}
+
+__global__ void __launch_bounds__(256) sgm_we12_kernel(We12Args a)
+{
+    __shared__ u32 s_lut[256];
+    s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
+    __syncthreads();
+    // blockIdx.x enumerates (16-row block, direction, frame); XCD-aware like sgm_paths_kernel: frame f -> XCD f % 8
+    const int nrb = a.Hp / 16, per_frame = nrb * 2;
+    int f, within;
+    if (a.B % 8 == 0) {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        f = (j / per_frame) * 8 + xcd;
+        within = j % per_frame;
+    } else {
+        f = blockIdx.x / per_frame;
+        within = blockIdx.x % per_frame;
+    }
+    const int east = within / nrb, rb = within % nrb;
+    const int y = rb * 16 + (int)(threadIdx.x >> 4);
+    const int lg = threadIdx.x & 15;
+    const int Wp = a.Wp;
+    const size_t fpix = (size_t)f * a.Hp * Wp;
+    We12Lane ln;
+    ln.dbase = 12 * lg;
+    ln.cr_fm512 = a.cr + fpix - 512; // (the census buffer has a 512-word guard in front: x - d < 0 reads)
+    ln.cl_f = a.cl + fpix;
+    ln.gray_f = a.gray + fpix;
+    const u32 rowoff = (u32)(y * Wp);
+    ln.cr_off = (rowoff + 512u - (u32)ln.dbase) * 4u;
+    ln.cl_off = rowoff * 4u;
+    ln.gray_off = rowoff;
+    ln.out_off = rowoff * 192u + (u32)ln.dbase;
+    u8 *out_f = a.out + (size_t)east * a.vol_elems + fpix * 192;
+    const u32 P1pk = pk_splat((u32)a.p1);
+    if (east) we12_line<true>(a, s_lut, ln, out_f, P1pk);
+    else we12_line<false>(a, s_lut, ln, out_f, P1pk);
+}
+
+static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut, int p1,
+                       void *paths)
+{
+    We12Args a;
+    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.out = (u8 *)paths;
+    a.Hp = Hp; a.Wp = Wp; a.B = B;
+    a.p1 = p1 < 0 ? 0 : (p1 > 231 ? 231 : p1); // exact for P1 >= P2max (see rsgm_launch_paths)
+    a.vol_elems = (size_t)B * Hp * Wp * 192;
+    sgm_we12_kernel<<<dim3((unsigned)(B * 2 * (Hp / 16))), 256, 0, ctx->stream>>>(a);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int GW, int DPL>
 static int launch_paths_t(vppx_ctx *ctx, PathArgs a, int B, bool from_dsi, int elem_bytes)
 {
@@ -1009,6 +1218,10 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
         return launch_paths_t<8, 16>(ctx, a, B, from_dsi, elem_bytes);
     }
     if (D <= 192) {
+        // W + E of the fused layout at D = 192: the register-window kernel (VPPX_WE12=0: the line kernel, for comparison)
+        static const int we12 = getenv("VPPX_WE12") ? atoi(getenv("VPPX_WE12")) : 1;
+        if (we12 && D == 192 && a.dir_mask == 0x11 && !from_dsi && elem_bytes == 1 && Hp % 16 == 0 && Wp % 16 == 0 && Wp >= 16 && gw_override <= 0)
+            return launch_we12(ctx, B, Hp, Wp, gray, cl, cr, p2lut, p1, paths);
         if (gw_override == 4) return launch_paths_t<4, 48>(ctx, a, B, from_dsi, elem_bytes);
         // fewer than 8 frames do not fill the chip with 8 lanes per pixel (1920 waves per frame): twice the
         // waves at 7 waves/SIMD win below that (B=1: 0.45 vs 0.60 ms), 8 x 24 wins from B=16 on (-5 %)
