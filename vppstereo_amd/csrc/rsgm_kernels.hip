@@ -968,34 +968,30 @@ struct We12State {
     u32 GI[4];
 };
 
-// Addresses are "wave-uniform base + 32-bit lane offset" (scalar-base addressing: the position along the line is uniform,
-// what differs between lanes is the row and the disparity chunk), so a step spends no vector arithmetic on them.
+// Addresses are "buffer resource of the frame + scalar position along the line + 32-bit lane offset" (what differs between
+// lanes is the row and the disparity chunk; the position is wave-uniform), so a step spends no vector arithmetic on them.
+struct We12Lane {
+    __amdgpu_buffer_rsrc_t cr, cl, gray, out; // the frame's right census (starting 512 words early), left census, gray image, volume
+    int cr_off;          // lane offsets in bytes: (row * Wp - dbase + 512) * 4, row * Wp * 4, row * Wp, row * Wp * 192 + dbase
+    int cl_off, gray_off, out_off;
+    int dbase;
+};
+
 template <bool EAST>
-__device__ __forceinline__ void we12_load_quad(u32 (&T)[4], const u32 *cr_fm512 /* frame's right census - 512 words */, u32 lane_cr_off,
-                                               int Q, int Wp)
+__device__ __forceinline__ void we12_load_quad(u32 (&T)[4], const We12Lane &ln, int Q, int Wp)
 {
-    typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));
     if (!EAST) { // steps x = 4Q .. 4Q+3 bring in cr[x - dbase]
-        const u32x4 v = *(const u32x4 *)((const char *)(cr_fm512 + 4 * Q) + (size_t)lane_cr_off);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off, 16 * Q, 0);
         T[0] = v.x; T[1] = v.y; T[2] = v.z; T[3] = v.w;
     } else {     // steps x = Wp-1-4Q-i bring in cr[x - dbase - 11]: descending, one word off a 16-byte boundary
-        const u32x4a v = *(const u32x4a *)((const char *)(cr_fm512 + (Wp - 15 - 4 * Q)) + (size_t)lane_cr_off);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off, 4 * (Wp - 15 - 4 * Q), 0);
         T[0] = v.w; T[1] = v.z; T[2] = v.y; T[3] = v.x;
     }
 }
 
-struct We12Lane {
-    const u32 *cr_fm512; // uniform bases of the frame
-    const u32 *cl_f;
-    const u8 *gray_f;
-    u32 cr_off;          // lane offsets in bytes: (row * Wp - dbase + 512) * 4, row * Wp * 4, row * Wp, row * Wp * 192 + dbase
-    u32 cl_off, gray_off, out_off;
-    int dbase;
-};
-
 template <bool EAST, int K>
-__device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const We12Lane &ln, u8 *out_g /* uniform: the group's first pixel */,
-                                          int t0, int Wp, u32 P1pk, bool masked, int nquads)
+__device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const We12Lane &ln, int t0, int Wp, u32 P1pk, bool masked,
+                                          int nquads)
 {
     const int t = t0 + K;
     if (t >= Wp) return; // (wave-uniform: the last group of a line whose length is no multiple of 12)
@@ -1009,13 +1005,13 @@ __device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const
         int ta = t + 4;
         ta = ta < Wp ? ta : Wp - 1;
         const int xa = EAST ? Wp - 1 - ta : ta;
-        st.CL[K % 4] = *(const u32 *)((const char *)(ln.cl_f + xa) + (size_t)ln.cl_off);
-        st.GI[K % 4] = *((const u8 *)(ln.gray_f + xa) + (size_t)ln.gray_off);
+        st.CL[K % 4] = __builtin_amdgcn_raw_buffer_load_b32(ln.cl, ln.cl_off, 4 * xa, 0);
+        st.GI[K % 4] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
     }
     if (K % 4 == 0) {
         int Q = t / 4 + 2;
         Q = Q < nquads ? Q : nquads - 1;
-        we12_load_quad<EAST>(st.T[(K / 4 + 2) % 3], ln.cr_fm512, ln.cr_off, Q, Wp);
+        we12_load_quad<EAST>(st.T[(K / 4 + 2) % 3], ln, Q, Wp);
     }
     // ---- matching costs of the lane's 12 disparities: pair i = (dbase + 2i, dbase + 2i + 1)
     u32 C[6];
@@ -1043,15 +1039,13 @@ __device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const
     sgm_update<6, true, 16, true, true>(st.L, C, C, C, P1pk, P2pk, st.minpk, inact, false, false);
     st.prevI = I;
     // ---- the pixel's 12 bytes of this lane (values < 256 by construction of the byte variant), streaming store
-    u32 bw[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) bw[i] = __builtin_amdgcn_perm(st.L[2 * i + 1], st.L[2 * i], 0x06040200u);
-    store_words_nt<3>((u32 *)(out_g + (EAST ? -K : K) * 192 + (size_t)ln.out_off), bw);
+    const u32x3 bw = {__builtin_amdgcn_perm(st.L[1], st.L[0], 0x06040200u), __builtin_amdgcn_perm(st.L[3], st.L[2], 0x06040200u),
+                      __builtin_amdgcn_perm(st.L[5], st.L[4], 0x06040200u)};
+    __builtin_amdgcn_raw_buffer_store_b96(bw, ln.out, ln.out_off, 192 * x, 2 /* nt */);
 }
 
 template <bool EAST>
-__device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, const We12Lane &ln, u8 *out_f /* uniform: frame of this direction's volume */,
-                                          u32 P1pk)
+__device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, const We12Lane &ln, u32 P1pk)
 {
     const int Wp = a.Wp, nquads = Wp / 4;
     We12State st;
@@ -1060,48 +1054,52 @@ __device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, c
     st.minpk = 0;
     {
         // the window before the first step: W needs cr[-dbase-11 .. -dbase-1] in slots 1..11, E needs cr[Wp-1-dbase-j] in slot j
-        const u32 *p = (const u32 *)((const char *)(ln.cr_fm512 + (EAST ? Wp - 12 : -12)) + (size_t)ln.cr_off);
-        const u32x4 v0 = *(const u32x4 *)p, v1 = *(const u32x4 *)(p + 4), v2 = *(const u32x4 *)(p + 8);
+        const int so = 4 * (EAST ? Wp - 12 : -12);
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off + so, 0, 0);
+        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off + so + 16, 0, 0);
+        const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off + so + 32, 0, 0);
         const u32 blk[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
         for (int m = 0; m < 12; m++) st.r[m] = EAST ? blk[11 - m] : blk[m];
     }
-    we12_load_quad<EAST>(st.T[0], ln.cr_fm512, ln.cr_off, 0, Wp);
-    we12_load_quad<EAST>(st.T[1], ln.cr_fm512, ln.cr_off, 1 < nquads ? 1 : 0, Wp);
+    we12_load_quad<EAST>(st.T[0], ln, 0, Wp);
+    we12_load_quad<EAST>(st.T[1], ln, 1 < nquads ? 1 : 0, Wp);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int ta = i < Wp ? i : Wp - 1;
         const int xa = EAST ? Wp - 1 - ta : ta;
-        st.CL[i] = *(const u32 *)((const char *)(ln.cl_f + xa) + (size_t)ln.cl_off);
-        st.GI[i] = *((const u8 *)(ln.gray_f + xa) + (size_t)ln.gray_off);
+        st.CL[i] = __builtin_amdgcn_raw_buffer_load_b32(ln.cl, ln.cl_off, 4 * xa, 0);
+        st.GI[i] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
     }
     st.prevI = st.GI[0];
     for (int t0 = 0; t0 < Wp; t0 += 12) {
         // any step of this group in the first 191 columns?  (W: at the start of the line, E: at its end)
         const bool masked = EAST ? (Wp - 1 - (t0 + 11) < 191) : (t0 < 191);
-        u8 *out_g = out_f + (size_t)(EAST ? Wp - 1 - t0 : t0) * 192;
-        we12_step<EAST, 0>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 1>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 2>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 3>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 4>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 5>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 6>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 7>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 8>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 9>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 10>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 11>(st, s_lut, ln, out_g, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 0>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 1>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 2>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 3>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 4>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 5>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 6>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 7>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 8>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 9>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 10>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, 11>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
     }
 }
 
-__global__ void __launch_bounds__(256) sgm_we12_kernel(We12Args a)
+#ifndef WE12_WPB
+#define WE12_WPB 1 // waves per block (1: 0.875 ms per 16 frames, 4: 0.90 -- single-wave blocks spread more evenly over the SIMDs)
+#endif
+__global__ void __launch_bounds__(64 * WE12_WPB) sgm_we12_kernel(We12Args a)
 {
     __shared__ u32 s_lut[256];
-    s_lut[threadIdx.x] = pk_splat(a.p2lut[threadIdx.x]);
+    for (int i = threadIdx.x; i < 256; i += 64 * WE12_WPB) s_lut[i] = pk_splat(a.p2lut[i]);
     __syncthreads();
-    // blockIdx.x enumerates (16-row block, direction, frame); XCD-aware like sgm_paths_kernel: frame f -> XCD f % 8
-    const int nrb = a.Hp / 16, per_frame = nrb * 2;
+    // blockIdx.x enumerates (row block, direction, frame); XCD-aware like sgm_paths_kernel: frame f -> XCD f % 8
+    const int nrb = a.Hp / (4 * WE12_WPB), per_frame = nrb * 2;
     int f, within;
     if (a.B % 8 == 0) {
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
@@ -1112,24 +1110,26 @@ __global__ void __launch_bounds__(256) sgm_we12_kernel(We12Args a)
         within = blockIdx.x % per_frame;
     }
     const int east = within / nrb, rb = within % nrb;
-    const int y = rb * 16 + (int)(threadIdx.x >> 4);
+    const int y = rb * (4 * WE12_WPB) + (int)(threadIdx.x >> 4);
     const int lg = threadIdx.x & 15;
     const int Wp = a.Wp;
     const size_t fpix = (size_t)f * a.Hp * Wp;
+    const int npf = a.Hp * Wp; // pixels of a frame (< 2^24: the volume offsets below stay below 2^32)
     We12Lane ln;
     ln.dbase = 12 * lg;
-    ln.cr_fm512 = a.cr + fpix - 512; // (the census buffer has a 512-word guard in front: x - d < 0 reads)
-    ln.cl_f = a.cl + fpix;
-    ln.gray_f = a.gray + fpix;
-    const u32 rowoff = (u32)(y * Wp);
-    ln.cr_off = (rowoff + 512u - (u32)ln.dbase) * 4u;
-    ln.cl_off = rowoff * 4u;
+    // (the census buffer has a 512-word guard in front: x - d < 0 reads; the resources end with the frame)
+    ln.cr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cr + fpix - 512), 0, (npf + 512) * 4, 0x00020000);
+    ln.cl = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cl + fpix), 0, npf * 4, 0x00020000);
+    ln.gray = __builtin_amdgcn_make_buffer_rsrc((void *)(a.gray + fpix), 0, npf, 0x00020000);
+    ln.out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)east * a.vol_elems + fpix * 192), 0, (int)((u32)npf * 192u), 0x00020000);
+    const int rowoff = y * Wp;
+    ln.cr_off = (rowoff + 512 - ln.dbase) * 4;
+    ln.cl_off = rowoff * 4;
     ln.gray_off = rowoff;
-    ln.out_off = rowoff * 192u + (u32)ln.dbase;
-    u8 *out_f = a.out + (size_t)east * a.vol_elems + fpix * 192;
+    ln.out_off = rowoff * 192 + ln.dbase;
     const u32 P1pk = pk_splat((u32)a.p1);
-    if (east) we12_line<true>(a, s_lut, ln, out_f, P1pk);
-    else we12_line<false>(a, s_lut, ln, out_f, P1pk);
+    if (east) we12_line<true>(a, s_lut, ln, P1pk);
+    else we12_line<false>(a, s_lut, ln, P1pk);
 }
 
 static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut, int p1,
@@ -1140,7 +1140,7 @@ static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, con
     a.Hp = Hp; a.Wp = Wp; a.B = B;
     a.p1 = p1 < 0 ? 0 : (p1 > 231 ? 231 : p1); // exact for P1 >= P2max (see rsgm_launch_paths)
     a.vol_elems = (size_t)B * Hp * Wp * 192;
-    sgm_we12_kernel<<<dim3((unsigned)(B * 2 * (Hp / 16))), 256, 0, ctx->stream>>>(a);
+    sgm_we12_kernel<<<dim3((unsigned)(B * 2 * (Hp / (4 * WE12_WPB)))), 64 * WE12_WPB, 0, ctx->stream>>>(a);
     VPPX_CHECK_LAUNCH();
     return 0;
 }
