@@ -620,7 +620,7 @@ def run_rank(args):
                "algorithmic_bytes": f"{agg_bytes} B/cell = SURVEY 8d's 10 B/cell of the 8-path aggregation, pro rata for the paths this launch "
                              f"carries: {round(cells_launch * agg_bytes / 1e9, 3)} GB per launch / kernel_ms vs 8 TB/s (a byte-count "
                              "convention, not a utilisation: see valu and hbm_frac_of_peak)",
-               "other_aggregation_launch_ms": ({"sgm_paths_kernel (W, E)": {"in_step": round(we_ms_in_step, 4) if we_n else None,
+               "other_aggregation_launch_ms": ({("sgm_we12_kernel (W, E)" if D in (128, 192, 256) else "sgm_paths_kernel (W, E)"): {"in_step": round(we_ms_in_step, 4) if we_n else None,
                                                                             "launches_timed": we_n, "back_to_back": round(we_ms, 4)}}
                                                if fused else None),
                "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,

@@ -953,17 +953,20 @@ struct We12Args {
     const u32 *cl;
     const u32 *cr;
     const u16 *p2lut;
-    u8 *out;          // [2][B][Hp][Wp][192]: W, E
+    u8 *out;          // [2][B][Hp][Wp][D]: W, E
     int Hp, Wp, p1, B;
     size_t vol_elems;
 };
 
+// DPL = disparities per lane = length of the window = steps per unrolled group (8, 12, 16: D = 128, 192, 256)
+template <int DPL>
 struct We12State {
-    u32 L[6];
+    static constexpr int NQ = DPL / 4; // quads of steps per group = sets of prefetched words
+    u32 L[DPL / 2];
     u32 minpk;
     u32 prevI;
-    u32 r[12];    // the window, rotating
-    u32 T[3][4];  // new right-census words of this quad of steps and of the two quads ahead
+    u32 r[DPL];   // the window, rotating
+    u32 T[NQ][4]; // new right-census words of this quad of steps and of the quads ahead
     u32 CL[4];    // left census word / gray value of this step and of the three ahead
     u32 GI[4];
 };
@@ -972,32 +975,34 @@ struct We12State {
 // lanes is the row and the disparity chunk; the position is wave-uniform), so a step spends no vector arithmetic on them.
 struct We12Lane {
     __amdgpu_buffer_rsrc_t cr, cl, gray, out; // the frame's right census (starting 512 words early), left census, gray image, volume
-    int cr_off;          // lane offsets in bytes: (row * Wp - dbase + 512) * 4, row * Wp * 4, row * Wp, row * Wp * 192 + dbase
+    int cr_off;          // lane offsets in bytes: (row * Wp - dbase + 512) * 4, row * Wp * 4, row * Wp, row * Wp * D + dbase
     int cl_off, gray_off, out_off;
     int dbase;
 };
 
-template <bool EAST>
+template <bool EAST, int DPL>
 __device__ __forceinline__ void we12_load_quad(u32 (&T)[4], const We12Lane &ln, int Q, int Wp)
 {
     if (!EAST) { // steps x = 4Q .. 4Q+3 bring in cr[x - dbase]
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off, 16 * Q, 0);
         T[0] = v.x; T[1] = v.y; T[2] = v.z; T[3] = v.w;
-    } else {     // steps x = Wp-1-4Q-i bring in cr[x - dbase - 11]: descending, one word off a 16-byte boundary
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off, 4 * (Wp - 15 - 4 * Q), 0);
+    } else {     // steps x = Wp-1-4Q-i bring in cr[x - dbase - (DPL-1)]: descending, one word off a 16-byte boundary
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off, 4 * (Wp - DPL - 3 - 4 * Q), 0);
         T[0] = v.w; T[1] = v.z; T[2] = v.y; T[3] = v.x;
     }
 }
 
-template <bool EAST, int K>
-__device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const We12Lane &ln, int t0, int Wp, u32 P1pk, bool masked,
+template <bool EAST, int DPL, int K>
+__device__ __forceinline__ void we12_step(We12State<DPL> &st, const u32 *s_lut, const We12Lane &ln, int t0, int Wp, u32 P1pk, bool masked,
                                           int nquads)
 {
+    constexpr int NP = DPL / 2, NQ = DPL / 4, D = 16 * DPL;
+    constexpr int AHEAD = NQ >= 3 ? 2 : 1; // quads between the load of a word and its step
     const int t = t0 + K;
-    if (t >= Wp) return; // (wave-uniform: the last group of a line whose length is no multiple of 12)
+    if (t >= Wp) return; // (wave-uniform: the last group of a line whose length is no multiple of DPL)
     const int x = EAST ? Wp - 1 - t : t;
     // ---- the step's new right-census word enters the window
-    st.r[EAST ? (K + 11) % 12 : K] = st.T[K / 4][K % 4];
+    st.r[EAST ? (K + DPL - 1) % DPL : K] = st.T[K / 4][K % 4];
     const u32 clv = st.CL[K % 4];
     const u32 I = st.GI[K % 4];
     // ---- operands of the steps ahead (scalar, clamped positions: t is wave-uniform)
@@ -1008,17 +1013,17 @@ __device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const
         st.CL[K % 4] = __builtin_amdgcn_raw_buffer_load_b32(ln.cl, ln.cl_off, 4 * xa, 0);
         st.GI[K % 4] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
     }
-    if (K % 4 == 0) {
-        int Q = t / 4 + 2;
+    if (K % 4 == 0) { // (the set refilled here held the words of the quad before this one)
+        int Q = t / 4 + AHEAD;
         Q = Q < nquads ? Q : nquads - 1;
-        we12_load_quad<EAST>(st.T[(K / 4 + 2) % 3], ln, Q, Wp);
+        we12_load_quad<EAST, DPL>(st.T[(K / 4 + AHEAD) % NQ], ln, Q, Wp);
     }
-    // ---- matching costs of the lane's 12 disparities: pair i = (dbase + 2i, dbase + 2i + 1)
-    u32 C[6];
+    // ---- matching costs of the lane's DPL disparities: pair i = (dbase + 2i, dbase + 2i + 1)
+    u32 C[NP];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const u32 w0 = st.r[EAST ? (K + 2 * i) % 12 : (K - 2 * i + 24) % 12];
-        const u32 w1 = st.r[EAST ? (K + 2 * i + 1) % 12 : (K - 2 * i - 1 + 24) % 12];
+    for (int i = 0; i < NP; i++) {
+        const u32 w0 = st.r[EAST ? (K + 2 * i) % DPL : (K - 2 * i + 2 * DPL) % DPL];
+        const u32 w1 = st.r[EAST ? (K + 2 * i + 1) % DPL : (K - 2 * i - 1 + 2 * DPL) % DPL];
         const u32 c0 = __popc(clv ^ w0), c1 = __popc(clv ^ w1);
         C[i] = (c1 << 16) | c0;
     }
@@ -1026,7 +1031,7 @@ __device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const
                   // compiler from turning it into a dozen selects that every step would execute.)
         const int lim = x - ln.dbase;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < NP; i++) {
             const u32 keep = (2 * i <= lim ? 0xFFFFu : 0u) | (2 * i + 1 <= lim ? 0xFFFF0000u : 0u);
             u32 c = (C[i] & keep) | (~keep & (INVALID_DISP_COST | (INVALID_DISP_COST << 16)));
             asm volatile("" : "+v"(c));
@@ -1035,35 +1040,54 @@ __device__ __forceinline__ void we12_step(We12State &st, const u32 *s_lut, const
     }
     const u32 di = __builtin_amdgcn_sad_u8(I, st.prevI, 0u);
     const u32 P2pk = s_lut[di];
-    const u32 inact[6] = {0, 0, 0, 0, 0, 0};
-    sgm_update<6, true, 16, true, true>(st.L, C, C, C, P1pk, P2pk, st.minpk, inact, false, false);
+    u32 inact[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) inact[i] = 0;
+    sgm_update<NP, true, 16, true, true>(st.L, C, C, C, P1pk, P2pk, st.minpk, inact, false, false);
     st.prevI = I;
-    // ---- the pixel's 12 bytes of this lane (values < 256 by construction of the byte variant), streaming store
-    const u32x3 bw = {__builtin_amdgcn_perm(st.L[1], st.L[0], 0x06040200u), __builtin_amdgcn_perm(st.L[3], st.L[2], 0x06040200u),
-                      __builtin_amdgcn_perm(st.L[5], st.L[4], 0x06040200u)};
-    __builtin_amdgcn_raw_buffer_store_b96(bw, ln.out, ln.out_off, 192 * x, 2 /* nt */);
+    // ---- the pixel's DPL bytes of this lane (values < 256 by construction of the byte variant), streaming store
+    u32 bw[NP / 2];
+#pragma unroll
+    for (int i = 0; i < NP / 2; i++) bw[i] = __builtin_amdgcn_perm(st.L[2 * i + 1], st.L[2 * i], 0x06040200u);
+    if constexpr (DPL == 8) __builtin_amdgcn_raw_buffer_store_b64(u32x2{bw[0], bw[1]}, ln.out, ln.out_off, D * x, 2 /* nt */);
+    else if constexpr (DPL == 12) __builtin_amdgcn_raw_buffer_store_b96(u32x3{bw[0], bw[1], bw[2]}, ln.out, ln.out_off, D * x, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(u32x4{bw[0], bw[1], bw[2], bw[3]}, ln.out, ln.out_off, D * x, 2);
 }
 
-template <bool EAST>
+template <bool EAST, int DPL, int K0, int KN>
+__device__ __forceinline__ void we12_steps(We12State<DPL> &st, const u32 *s_lut, const We12Lane &ln, int t0, int Wp, u32 P1pk, bool masked,
+                                           int nquads)
+{
+    if constexpr (K0 < KN) {
+        we12_step<EAST, DPL, K0>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_steps<EAST, DPL, K0 + 1, KN>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+    }
+}
+
+template <bool EAST, int DPL>
 __device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, const We12Lane &ln, u32 P1pk)
 {
+    constexpr int NQ = DPL / 4, D = 16 * DPL;
+    constexpr int AHEAD = NQ >= 3 ? 2 : 1;
     const int Wp = a.Wp, nquads = Wp / 4;
-    We12State st;
+    We12State<DPL> st;
 #pragma unroll
-    for (int i = 0; i < 6; i++) st.L[i] = 0; // first step: L = 0, min = 0 => L = C
+    for (int i = 0; i < DPL / 2; i++) st.L[i] = 0; // first step: L = 0, min = 0 => L = C
     st.minpk = 0;
     {
-        // the window before the first step: W needs cr[-dbase-11 .. -dbase-1] in slots 1..11, E needs cr[Wp-1-dbase-j] in slot j
-        const int so = 4 * (EAST ? Wp - 12 : -12);
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off + so, 0, 0);
-        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off + so + 16, 0, 0);
-        const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off + so + 32, 0, 0);
-        const u32 blk[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        // the window before the first step: W needs cr[-dbase-(DPL-1) .. -dbase-1] in slots 1..DPL-1, E needs cr[Wp-1-dbase-j] in slot j
+        const int so = 4 * (EAST ? Wp - DPL : -DPL);
+        u32 blk[DPL];
 #pragma unroll
-        for (int m = 0; m < 12; m++) st.r[m] = EAST ? blk[11 - m] : blk[m];
+        for (int q = 0; q < NQ; q++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off + so + 16 * q, 0, 0);
+            blk[4 * q] = v.x; blk[4 * q + 1] = v.y; blk[4 * q + 2] = v.z; blk[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int m = 0; m < DPL; m++) st.r[m] = EAST ? blk[DPL - 1 - m] : blk[m];
     }
-    we12_load_quad<EAST>(st.T[0], ln, 0, Wp);
-    we12_load_quad<EAST>(st.T[1], ln, 1 < nquads ? 1 : 0, Wp);
+#pragma unroll
+    for (int q = 0; q < AHEAD; q++) we12_load_quad<EAST, DPL>(st.T[q], ln, q < nquads ? q : nquads - 1, Wp);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int ta = i < Wp ? i : Wp - 1;
@@ -1072,29 +1096,20 @@ __device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, c
         st.GI[i] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
     }
     st.prevI = st.GI[0];
-    for (int t0 = 0; t0 < Wp; t0 += 12) {
-        // any step of this group in the first 191 columns?  (W: at the start of the line, E: at its end)
-        const bool masked = EAST ? (Wp - 1 - (t0 + 11) < 191) : (t0 < 191);
-        we12_step<EAST, 0>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 1>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 2>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 3>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 4>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 5>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 6>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 7>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 8>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 9>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 10>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_step<EAST, 11>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+    for (int t0 = 0; t0 < Wp; t0 += DPL) {
+        // any step of this group in the first D-1 columns?  (W: at the start of the line, E: at its end)
+        const bool masked = EAST ? (Wp - 1 - (t0 + DPL - 1) < D - 1) : (t0 < D - 1);
+        we12_steps<EAST, DPL, 0, DPL>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
     }
 }
 
 #ifndef WE12_WPB
 #define WE12_WPB 1 // waves per block (1: 0.875 ms per 16 frames, 4: 0.90 -- single-wave blocks spread more evenly over the SIMDs)
 #endif
+template <int DPL>
 __global__ void __launch_bounds__(64 * WE12_WPB) sgm_we12_kernel(We12Args a)
 {
+    constexpr int D = 16 * DPL;
     __shared__ u32 s_lut[256];
     for (int i = threadIdx.x; i < 256; i += 64 * WE12_WPB) s_lut[i] = pk_splat(a.p2lut[i]);
     __syncthreads();
@@ -1114,33 +1129,36 @@ __global__ void __launch_bounds__(64 * WE12_WPB) sgm_we12_kernel(We12Args a)
     const int lg = threadIdx.x & 15;
     const int Wp = a.Wp;
     const size_t fpix = (size_t)f * a.Hp * Wp;
-    const int npf = a.Hp * Wp; // pixels of a frame (< 2^24: the volume offsets below stay below 2^32)
+    const int npf = a.Hp * Wp; // pixels of a frame (npf * D < 2^32: checked by the launcher)
     We12Lane ln;
-    ln.dbase = 12 * lg;
+    ln.dbase = DPL * lg;
     // (the census buffer has a 512-word guard in front: x - d < 0 reads; the resources end with the frame)
     ln.cr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cr + fpix - 512), 0, (npf + 512) * 4, 0x00020000);
     ln.cl = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cl + fpix), 0, npf * 4, 0x00020000);
     ln.gray = __builtin_amdgcn_make_buffer_rsrc((void *)(a.gray + fpix), 0, npf, 0x00020000);
-    ln.out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)east * a.vol_elems + fpix * 192), 0, (int)((u32)npf * 192u), 0x00020000);
+    ln.out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)east * a.vol_elems + fpix * D), 0, (int)((u32)npf * (u32)D), 0x00020000);
     const int rowoff = y * Wp;
     ln.cr_off = (rowoff + 512 - ln.dbase) * 4;
     ln.cl_off = rowoff * 4;
     ln.gray_off = rowoff;
-    ln.out_off = rowoff * 192 + ln.dbase;
+    ln.out_off = rowoff * D + ln.dbase;
     const u32 P1pk = pk_splat((u32)a.p1);
-    if (east) we12_line<true>(a, s_lut, ln, P1pk);
-    else we12_line<false>(a, s_lut, ln, P1pk);
+    if (east) we12_line<true, DPL>(a, s_lut, ln, P1pk);
+    else we12_line<false, DPL>(a, s_lut, ln, P1pk);
 }
 
-static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut, int p1,
+static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut, int p1,
                        void *paths)
 {
     We12Args a;
     a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.out = (u8 *)paths;
     a.Hp = Hp; a.Wp = Wp; a.B = B;
     a.p1 = p1 < 0 ? 0 : (p1 > 231 ? 231 : p1); // exact for P1 >= P2max (see rsgm_launch_paths)
-    a.vol_elems = (size_t)B * Hp * Wp * 192;
-    sgm_we12_kernel<<<dim3((unsigned)(B * 2 * (Hp / (4 * WE12_WPB)))), 64 * WE12_WPB, 0, ctx->stream>>>(a);
+    a.vol_elems = (size_t)B * Hp * Wp * D;
+    const dim3 grid((unsigned)(B * 2 * (Hp / (4 * WE12_WPB))));
+    if (D == 128) sgm_we12_kernel<8><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);
+    else if (D == 192) sgm_we12_kernel<12><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);
+    else sgm_we12_kernel<16><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);
     VPPX_CHECK_LAUNCH();
     return 0;
 }
@@ -1208,6 +1226,13 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
         const char *e = getenv("VPPX_GW"); // experiment knob: lanes per pixel (other layouts per D range)
         gw_override = e ? atoi(e) : 0;
     }
+    {
+        // W + E of the fused layout at D = 128 / 192 / 256: the register-window kernel (VPPX_WE12=0: the line kernel, for comparison)
+        static const int we12 = getenv("VPPX_WE12") ? atoi(getenv("VPPX_WE12")) : 1;
+        if (we12 && (D == 128 || D == 192 || D == 256) && a.dir_mask == 0x11 && !from_dsi && elem_bytes == 1 && Hp % 16 == 0 && Wp % 16 == 0 &&
+            Wp >= 16 && gw_override <= 0)
+            return launch_we12(ctx, B, Hp, Wp, D, gray, cl, cr, p2lut, p1, paths);
+    }
     if (D <= 64) {
         if (gw_override == 8) return launch_paths_t<8, 8>(ctx, a, B, from_dsi, elem_bytes);
         return launch_paths_t<4, 16>(ctx, a, B, from_dsi, elem_bytes);
@@ -1218,10 +1243,6 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
         return launch_paths_t<8, 16>(ctx, a, B, from_dsi, elem_bytes);
     }
     if (D <= 192) {
-        // W + E of the fused layout at D = 192: the register-window kernel (VPPX_WE12=0: the line kernel, for comparison)
-        static const int we12 = getenv("VPPX_WE12") ? atoi(getenv("VPPX_WE12")) : 1;
-        if (we12 && D == 192 && a.dir_mask == 0x11 && !from_dsi && elem_bytes == 1 && Hp % 16 == 0 && Wp % 16 == 0 && Wp >= 16 && gw_override <= 0)
-            return launch_we12(ctx, B, Hp, Wp, gray, cl, cr, p2lut, p1, paths);
         if (gw_override == 4) return launch_paths_t<4, 48>(ctx, a, B, from_dsi, elem_bytes);
         // fewer than 8 frames do not fill the chip with 8 lanes per pixel (1920 waves per frame): twice the
         // waves at 7 waves/SIMD win below that (B=1: 0.45 vs 0.60 ms), 8 x 24 wins from B=16 on (-5 %)

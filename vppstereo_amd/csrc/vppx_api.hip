@@ -485,13 +485,16 @@ static int check_rsgm_params(const VppxRsgmParams &p)
 // Would a call of this geometry take the fused layout (W/E line-parallel + the lock-step vertical kernel)?  use_vert: -1
 // (default) = pick by shape, 0 = eight line-parallel paths, 3 = fused whenever the shape allows it.  Probes the device on
 // the first question (block placement, residency).
+// frames per launch from which the fused layout wins (540x960x192, ms per frame 8-path / fused, round 4: 4 frames 0.44 / 0.46,
+// 6 frames 0.43 / 0.39, 8 frames 0.37 / 0.32)
+#define VPPX_FUSED_MIN_FRAMES 6
 static int fused_layout_wanted(vppx_ctx *ctx, const RsgmGeom &g, int maxp2, bool *out)
 {
     int rc;
     *out = false;
     const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
     bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
-    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8))) {
+    if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= VPPX_FUSED_MIN_FRAMES))) {
         // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes
         // (8 XCDs, round-robin), and how many blocks of this build of the kernel does one XCD hold?
         if ((rc = v3_probe_once(ctx))) return rc;
@@ -504,7 +507,7 @@ static int fused_layout_wanted(vppx_ctx *ctx, const RsgmGeom &g, int maxp2, bool
     // with groups of the 16-pixels-per-wave kernel (round 3, ms per step 8-path / fused 8 px per wave / fused 16 px per wave:
     // 540x960 B=32 D=64 7.4 / 7.5 / 6.8, D=128 10.6 / 9.3 / 9.0; 375x1242x192 B=32 12.1 / 10.4 / 10.2; 1536x2048x256 B=8
     // 28.7 / 32.0 / 23.1, B=16 56.4 / 64.4 / 46.1)
-    *out = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= 8 && (g.D == 128 || g.D == 192 || rsgm_vert3_wide(ctx, g.B, g.Wp, g.D))));
+    *out = v3_ok && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= VPPX_FUSED_MIN_FRAMES && (g.D == 128 || g.D == 192 || rsgm_vert3_wide(ctx, g.B, g.Wp, g.D))));
     return 0;
 }
 
@@ -874,7 +877,18 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     // frames per call (8-path layout, a GPU mostly idle during the aggregation) the next front stage starts early
     const bool alt = ctx->pipe_call && (ctx->pipe_parity & 1);
     if (ctx->pipe_call) ctx->pipe_parity ^= 1;
-    ctx->pipe_early = ctx->pipe_call && g.B < 8;
+    {
+        // (the next call's front stage starts next to this call's aggregation only when that is the line-parallel kernel: the
+        // lock-step kernel suffers from neighbours)
+        bool fused = false;
+        if (ctx->pipe_call && g.B < 8) {
+            u16 lut_tmp[256];
+            int mp2 = 0;
+            p2_lut_host(p, lut_tmp, &mp2);
+            if ((rc = fused_layout_wanted(ctx, g, mp2, &fused))) return rc;
+        }
+        ctx->pipe_early = ctx->pipe_call && g.B < 8 && !fused;
+    }
     if ((rc = ws_get(ctx, alt ? WS_GRAY_L2 : WS_GRAY_L, npp, &gl))) return rc;
     if ((rc = ws_get(ctx, alt ? WS_CENSUS_L2 : WS_CENSUS_L, npp, &cl))) return rc;
     if ((rc = ws_get(ctx, alt ? WS_CENSUS_R2 : WS_CENSUS_R, npp + 512, &cr_raw))) return rc; // 512-word guard in front (x-d < 0 reads)
