@@ -119,6 +119,36 @@ def test_forced_lockstep_timeout_is_reported_by_the_same_calls_sync():
     assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, dmax=D), out[0].cpu().numpy())
 
 
+def test_lost_lock_step_rests_on_the_line_kernel_then_tries_the_fused_layout_again():
+    """Contention is usually temporary: after a loss the context aggregates with the line-parallel kernel for 64 launches
+    (doubling with every loss), then tries the fused layout again.  With the forced give-up the retry loses again -- and says
+    so again, once."""
+    import torch
+    from vppstereo_amd._lib import VppxError
+    D = 192
+    eng = _engine(VPPX_VERT=3, VPPX_V3_SPIN_LIMIT=1)
+    ref = _engine(VPPX_VERT=0)
+    b, args = _small_batch(eng, B=8, H=40, W=96, seed=15)
+    want = ref.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D)).clone()
+    ref.synchronize()
+    eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
+    with pytest.raises(VppxError, match="lost its lock step.*next 64 aggregation launches"):
+        eng.synchronize()
+    for i in range(64):
+        out = eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
+        assert eng.uses_vert() == 0, i
+    eng.synchronize()
+    assert torch.equal(out, want) and eng.ctx.lockstep_failures == 1
+    lost = eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))     # the rest is over: fused again
+    assert eng.uses_vert() == 3
+    with pytest.raises(VppxError, match="next 128 aggregation launches"):
+        eng.synchronize()
+    assert eng.ctx.lockstep_failures == 2 and bool(torch.isnan(lost).all())
+    out = eng.vpp_rsgm(*args, seed=3, rsgm_kw=dict(dmax=D))
+    eng.synchronize()
+    assert eng.uses_vert() == 0 and torch.equal(out, want)
+
+
 def test_forced_lockstep_timeout_is_seen_by_status_and_by_the_next_call():
     """A caller that synchronises through torch asks vppx_status; one that does not ask at all gets the error from its
     next call into the hot path (before anything is queued)."""

@@ -31,15 +31,21 @@ def passes(tag, name):
 
 
 def big_avg(vals):
-    """average over the launches with the largest grid (the full-batch ones)"""
-    g = max(v[0] for v in vals)
-    sel = [v[1] for v in vals if v[0] == g]
+    """average over the launches of the timed loop: the grid size that carries the most work (launches x grid).  The bench
+    also makes one-frame calls and two unsplit 32-frame calls (stage timing); the loop's 16-frame parts outweigh both."""
+    import collections
+    by = collections.defaultdict(list)
+    for g, v in vals:
+        by[g].append(v)
+    g = max(by, key=lambda k: k * len(by[k]))
+    sel = by[g]
     return sum(sel) / len(sel), len(sel)
 
 
 def main():
     tag, out = sys.argv[1], sys.argv[2]
-    batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 32
+    batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 16   # frames per launch (a 32-frame step = 2 parts)
+    parts = int(sys.argv[sys.argv.index("--parts") + 1]) if "--parts" in sys.argv else 2
     fe, wr, sq = passes(tag, "FETCH_SIZE"), passes(tag, "WRITE_SIZE"), passes(tag, "SQ")
     kern = {}
     for k in sorted(set(fe) | set(wr) | set(sq)):
@@ -62,7 +68,7 @@ def main():
             for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
                 if c in d:
                     d[c.lower() + "_frac_of_wave_cycles"] = round(d[c] / d["SQ_WAVE_CYCLES"], 3)
-        kern[k] = {a: (round(b, 3 if a.endswith('_cycles') or a.startswith('hbm') else 1) if isinstance(b, float) else b) for a, b in d.items()}
+        kern[k] = {a: (round(b, 4 if a.startswith('kernel_ms') else (3 if a.endswith('_cycles') or a.startswith('hbm') else 1)) if isinstance(b, float) else b) for a, b in d.items()}
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
     except Exception:
@@ -72,14 +78,14 @@ def main():
     per_step = None
     ref_n = kern.get("sum_wta_lr_kernel", {}).get("launches")
     if ref_n:
-        per_step = round(sum(v["hbm_GB_per_launch"] * v.get("launches", 0) / ref_n for v in kern.values() if "hbm_GB_per_launch" in v), 3)
+        per_step = round(parts * sum(v["hbm_GB_per_launch"] * v.get("launches", 0) / ref_n for v in kern.values() if "hbm_GB_per_launch" in v), 3)
     doc = {"hbm_GB_per_step": per_step, "note": "rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ set, each its own run) of "
                    "`python3 bench.py` by tools/prof_round.sh; per-launch averages over the full-batch launches, summed over the "
                    "chip.  hbm_GB_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB.  SQ_* cycle counters are quad-cycles summed over waves.",
-           "commit": commit, "kernel_source_sha": bench.kernel_source_sha(), "batch": batch, "H": bench.H, "W": bench.W, "D": bench.D,
+           "commit": commit, "kernel_source_sha": bench.kernel_source_sha(), "batch": batch, "parts_per_step": parts, "H": bench.H, "W": bench.W, "D": bench.D,
            "kernels": kern}
     json.dump(doc, open(out, "w"), indent=1)
-    for k in ("sgm_paths_kernel", "sum_wta_lr_kernel"):
+    for k in ("sgm_vert4_kernel", "sgm_we12_kernel", "sum_wta_lr_kernel"):
         print(k, kern.get(k))
 
 

@@ -285,7 +285,8 @@ extern "C" int vppx_set_stream_legacy(vppx_ctx *ctx)
 // The fused aggregation kernel (sgm_vert3_kernel) reports a lost lock step -- a wave that waited longer than the bound
 // for its neighbour's record -- through a pinned host word.  Whoever looks at it first reports it: vppx_status,
 // vppx_synchronize, the host-pointer entry points after their own synchronisation, and the next call of the hot path.
-// The context then stays on the line-parallel kernel (vert3_broken) and a captured graph holding the launch is dropped.
+// The context then rests on the line-parallel kernel (vert3_rest aggregation launches, doubling with every loss) and a captured
+// graph holding the launch is dropped.
 static int lockstep_check(vppx_ctx *ctx)
 {
     if (!ctx->vert3_err || !ctx->vert3_err[0]) return 0;
@@ -294,7 +295,10 @@ static int lockstep_check(vppx_ctx *ctx)
     ctx->lockstep_failures++;
     ctx->lockstep_last_serial = serial;
     if (ctx->v3.ignore_lost) return 0; // measurement only (tools/agg_probe.py: the fused kernel's time without any neighbour wait)
-    ctx->vert3_broken = true;
+    // Contention is usually temporary (another process or stream held block slots of an XCD): the context rests on the
+    // line-parallel layout for a while, then tries the fused layout again; the rest doubles with every loss.
+    ctx->vert3_rest = ctx->vert3_backoff;
+    ctx->vert3_backoff = ctx->vert3_backoff < 4096 ? ctx->vert3_backoff * 2 : 4096;
     if (ctx->gexec) {
         (void)hipGraphExecDestroy(ctx->gexec);
         ctx->gexec = nullptr;
@@ -303,8 +307,8 @@ static int lockstep_check(vppx_ctx *ctx)
     ctx->have_lastkey = false;
     vppx_set_error("fused aggregation launch #%u lost its lock step (a wave waited longer than %d ms%s for its neighbour): the "
                    "disparities of that call are void, and so are those of fused calls queued behind it (last launch: #%u); "
-                   "the context uses the line-parallel aggregation kernel from now on",
-                   serial, ctx->v3.timeout_ms, ctx->v3.spin_limit ? " / VPPX_V3_SPIN_LIMIT polls" : "", ctx->v3.serial);
+                   "the context uses the line-parallel aggregation kernel for its next %d aggregation launches, then tries the fused layout again",
+                   serial, ctx->v3.timeout_ms, ctx->v3.spin_limit ? " / VPPX_V3_SPIN_LIMIT polls" : "", ctx->v3.serial, ctx->vert3_rest);
     return VPPX_E_HIP;
 }
 
@@ -493,7 +497,7 @@ static int fused_layout_wanted(vppx_ctx *ctx, const RsgmGeom &g, int maxp2, bool
     int rc;
     *out = false;
     const int elem_bytes = rsgm_paths_elem_bytes(g.D, maxp2);
-    bool v3_ok = !ctx->vert3_broken && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
+    bool v3_ok = !ctx->vert3_broken && ctx->vert3_rest <= 0 && elem_bytes == 1 && rsgm_vert3_supported(g.B, g.Hp, g.Wp, g.D, maxp2);
     if (v3_ok && !ctx->vert3_probed && !ctx->capturing && (ctx->use_vert == 3 || (ctx->use_vert < 0 && g.B >= VPPX_FUSED_MIN_FRAMES))) {
         // first fused launch of this context: does this device place consecutive block ids the way the kernel assumes
         // (8 XCDs, round-robin), and how many blocks of this build of the kernel does one XCD hold?
@@ -649,6 +653,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
     // B=32 13.3 / 11.7); a context whose fused launch once lost its lock step never uses it again.
     bool vert3;
     if ((rc = fused_layout_wanted(ctx, g, maxp2, &vert3))) return rc;
+    if (!vert3 && ctx->vert3_rest > 0 && which == 0) ctx->vert3_rest--; // resting after a lost lock step
     const bool vert = vert3 || (ctx->use_vert == 1 && elem_bytes == 1 && rsgm_vert_supported(g.D, maxp2) && g.D <= 192);
     ctx->last_vert = vert3 ? 3 : (vert ? 1 : 0);
     void *paths;
@@ -1315,7 +1320,7 @@ static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
         u16 lut[256];
         int maxp2 = 0;
         p2_lut_host(*rp, lut, &maxp2);
-        if (!ctx->vert3_broken && (ctx->vert3_probed || !ctx->capturing) && v3_probe_once(ctx) == 0 && !ctx->vert3_broken) {
+        if (!ctx->vert3_broken && ctx->vert3_rest <= 0 && (ctx->vert3_probed || !ctx->capturing) && v3_probe_once(ctx) == 0 && !ctx->vert3_broken) {
             const int fpr = rsgm_vert3_frames_per_round(ctx, g1.Wp, g1.D);
             bool fused = false;
             if (fpr >= 8 && fpr < B) {

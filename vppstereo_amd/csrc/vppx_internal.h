@@ -142,7 +142,9 @@ struct vppx_ctx {
     struct PipeCopy { void *dst; const void *src; size_t bytes; } pipe_copy[3];
     int n_pipe_copy = 0;
     unsigned *vert3_err = nullptr; // pinned host word the fused vertical kernel sets (to its launch serial) when a wave gave up waiting
-    bool vert3_broken = false;     // set once vert3_err was seen (or the XCD probe failed): the context stays on the line-parallel kernel
+    bool vert3_broken = false;     // the XCD / residency probe failed on this device: the context never uses the fused layout
+    int vert3_rest = 0;            // aggregations left on the line-parallel layout after a lost lock step, before the fused layout is tried again
+    int vert3_backoff = 64;        // ... doubling with every loss (64, 128, ... 4096)
     bool vert3_probed = false;     // rsgm_vert3_probe has run on this context's device
     long lockstep_failures = 0;    // fused launches that reported a lost lock step (vppx_lockstep_failures)
     unsigned lockstep_last_serial = 0; // serial of the launch the last report was about
