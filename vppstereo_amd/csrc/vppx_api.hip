@@ -377,6 +377,7 @@ extern "C" int vppx_enable_stage_timing(vppx_ctx *ctx, int enable)
 void stage_begin(vppx_ctx *ctx)
 {
     if (!ctx->stage_timing || ctx->capturing) return;
+    if (ctx->stage_append && ctx->n_stages > 0) return; // later part of a split batch: the times add up per stage
     ctx->n_stages = 0;
     (void)hipEventRecord(ctx->ev[0], ctx->stream);
 }
@@ -1314,7 +1315,7 @@ static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
     int q = 0;
     if (chunk_env > 0) {
         q = chunk_env;
-    } else if (chunk_env < 0 && !ctx->stage_timing && !ctx->is_child && B >= 16) {
+    } else if (chunk_env < 0 && !ctx->is_child && B >= 16) {
         RsgmGeom g1;
         make_geom(1, H, W, C, rp->dmax, g1);
         u16 lut[256];
@@ -1341,11 +1342,13 @@ static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
         VppxVppParams v2 = *vp;
         v2.seed = vp->seed + (uint32_t)lo; // frame f keeps srand(seed + f) whatever the split
         ctx->inputs_ev = inputs_ev;
+        ctx->stage_append = lo > 0;
         rc = vpp_rsgm_one(ctx, op, &v2, rp, nb, H, W, C, left + (size_t)lo * fpx * C, right + (size_t)lo * fpx * C,
                           g + (size_t)lo * fpx, g_occ ? g_occ + (size_t)lo * fpx : nullptr,
                           conf_out ? conf_out + (size_t)lo * fpx : nullptr,
                           l_vpp ? l_vpp + (size_t)lo * fpx * C : nullptr, r_vpp ? r_vpp + (size_t)lo * fpx * C : nullptr,
                           disp_out + (size_t)lo * fpx);
+        ctx->stage_append = false;
         if (rc) return rc;
         lo += nb;
     }

@@ -103,7 +103,7 @@ enum WsSlot {
     WS_NUM
 };
 
-#define VPPX_MAX_STAGES 24
+#define VPPX_MAX_STAGES 96
 #define VPPX_MAX_DEVICES 64 // power of two: per-device one-time initialisations are indexed by device id
 
 struct vppx_ctx {
@@ -205,6 +205,7 @@ struct vppx_ctx {
     long graph_replays = 0, graph_captures = 0;
     // stage timing
     bool stage_timing = false;
+    bool stage_append = false;     // the running call is a later part of a split batch: its marks follow the earlier parts'
     int n_stages = 0;
     hipEvent_t ev[VPPX_MAX_STAGES + 1];
     bool ev_created = false;
