@@ -133,9 +133,11 @@ int vppx_set_stream_legacy(vppx_ctx *ctx);
 
 /* Cross-call pipelining for streams of batches through vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev: with `on`, the front
  * stage of a call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the PREVIOUS call's
- * aggregation is done, i.e. next to that call's sum / WTA and post kernels (calls of fewer than 8 frames leave most of the
- * GPU idle during their aggregation: there the next front stage starts as soon as the previous one has delivered its
- * results, next to that aggregation; the gray / census images exist twice for this).  Safe by construction:
+ * aggregation is done, i.e. next to that call's sum / WTA and post kernels (calls that take the 8-path layout -- fewer than
+ * 6 frames -- leave most of the GPU idle during their aggregation: there the next front stage starts as soon as the previous
+ * one has delivered its results, next to that aggregation; the gray / census images exist twice for this).  A call of more
+ * frames than one batch quantum (vppx_batch_quantum) runs as consecutive parts of one quantum each, pipelined like separate
+ * calls; results do not depend on the split.  Safe by construction:
  *   - outputs keep the launch stream's order: the launch stream waits for the front stage, and everything the front stage
  *     produces for the caller (conf_out, l_vpp, r_vpp) is computed into library-owned buffers and copied to the caller's
  *     memory ON THE LAUNCH STREAM -- the front stream never writes caller memory, so buffers allocated per call by a
@@ -158,12 +160,15 @@ int vppx_inputs_ready_event(vppx_ctx *ctx, void *hip_event);
 int vppx_synchronize(vppx_ctx *ctx);
 /* Health of the asynchronous hot path, non-blocking.  The fused aggregation kernel (vppx_uses_vert() == 3) hands
  * diagonal path state between neighbouring waves in lock step; every wait is bounded (VPPX_V3_TIMEOUT_MS, default 250 ms
- * of wall clock per wait), and a wave that gives up marks its launch: the disparities of that call are void.  The mark is
- * reported -- VPPX_E_HIP, once -- by whichever of these looks first: vppx_status, vppx_synchronize, the next
- * vppx_occlusion_heuristic_dev / vppx_vpp_rsgm_dev / vppx_rsgm_dev call, or vppx_rsgm_host, which instead repeats its own
- * aggregation on the line-parallel kernel and returns correct results.  From then on the context aggregates with the
- * line-parallel kernel only.  After the caller has synchronised the stream (by any means) a 0 from vppx_status covers
- * every call made so far.  (No reference counterpart: aggregate_SSE, rsgm.py:61, is synchronous.) */
+ * of wall clock per wait), and a wave that gives up marks its launch: the disparities of that call are void -- and are
+ * overwritten with NaN by a kernel queued behind the call, so that nothing later on the stream can take them for a
+ * disparity map.  The mark is reported -- VPPX_E_HIP, once -- by whichever of these looks first: vppx_status,
+ * vppx_synchronize, the next vppx_occlusion_heuristic_dev / vppx_vpp_rsgm_dev / vppx_rsgm_dev call, or vppx_rsgm_host, which
+ * repeats its OWN aggregation on the line-parallel kernel and returns correct results (a mark left by an earlier
+ * asynchronous call is reported, not consumed).  The context then aggregates with the line-parallel kernel for its next 64
+ * aggregation launches (doubling with every further loss, at most 4096) and tries the fused layout again.  After the caller
+ * has synchronised the stream (by any means) a 0 from vppx_status covers every call made so far.  (No reference
+ * counterpart: aggregate_SSE, rsgm.py:61, is synchronous.) */
 int vppx_status(vppx_ctx *ctx);
 /* Number of fused launches that reported a lost lock step on this context so far. */
 long vppx_lockstep_failures(vppx_ctx *ctx);
@@ -332,9 +337,10 @@ int vppx_time_aggregate_frames(vppx_ctx *ctx);
 /* Same for one part of the stage: 1 = horizontal-path line kernel, 2 = the band launches of the
  * vertical/diagonal paths (fast path only). */
 int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, float *ms_out);
-/* Aggregation layout of the last fused / rsgm call: 0 = all 8 paths in the line-parallel kernel, 3 = W and E
- * line-parallel + N/NW/NE and S/SW/SE fused three at a time in the lock-step kernel (default for D = 128 / 192 from 8
- * frames per call on; environment VPPX_VERT = 0 / 3 forces a layout), 1 = the round-1 band-marching experiment
+/* Aggregation layout of the last fused / rsgm call: 0 = all 8 paths in the line-parallel kernel, 3 = N/NW/NE and
+ * S/SW/SE fused three at a time in the lock-step kernel + W and E line-parallel (register-window kernel for D = 128 / 192 /
+ * 256) (default for D = 128 / 192 from 6 frames per call on; environment VPPX_VERT = 0 / 3 forces a layout), 1 = the round-1
+ * band-marching experiment
  * (VPPX_VERT = 1).  All layouts give identical results. */
 int vppx_uses_vert(vppx_ctx *ctx);
 /* Which fused kernel the last call used: 16 = sgm_vert4_kernel (16 pixels per wave, 4 lanes per pixel: the default once a
