@@ -471,3 +471,35 @@ def test_full_size_odd_batches_take_the_fused_layout(B):
         ref.synchronize()
         assert ref.uses_vert() == 0
         assert torch.equal(outs[s], want), (B, s)
+
+
+@pytest.mark.parametrize("B,chunk", [(13, 5), (16, 8), (9, 4)])
+def test_parts_of_a_split_batch_equal_the_unsplit_call(B, chunk):
+    """A batch larger than one round of the lock-step kernel runs as consecutive parts (vppx_api.hip: vpp_rsgm_parts).  Forced
+    here with VPPX_CHUNK on small frames: every output of the call -- disparities, mask, patterned pair -- must equal the
+    unsplit call's (frame f draws from srand(seed + f) whatever the split), with and without the cross-call overlap."""
+    import torch
+    H, W, D = 48, 112, 192
+    split, whole = _engine(VPPX_CHUNK=chunk), _engine(VPPX_CHUNK=0)
+    b = synth.make_batch(B, H, W, D, 0.05, seed=77)
+    args = [_dev(split, b[k]) for k in ("left", "right", "hints")]
+    outs = {}
+    for name, eng in (("split", split), ("whole", whole)):
+        for piped in (False, True):
+            eng.set_pipeline(piped)
+            occ = torch.empty((B, H, W), dtype=torch.uint8, device=eng.device)
+            lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=eng.device)
+            rv = torch.empty_like(lv)
+            o = eng.vpp_rsgm(*args, g_occ="occlusion_heuristic", occ_out=occ, l_vpp=lv, r_vpp=rv, seed=5, rsgm_kw=dict(dmax=D, subpixel=1))
+            eng.synchronize()
+            outs[(name, piped)] = (o.clone(), occ, lv, rv)
+    ref = outs[("whole", False)]
+    for key, got in outs.items():
+        for a, w in zip(got, ref):
+            assert torch.equal(a, w), key
+    f = B - 1   # the last frame sits in the last part: its seed is 5 + f
+    conf = oracle.occlusion_heuristic(b["hints"][f])[1]
+    oracle.init_rand(5 + f)
+    lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], g_occ=conf)
+    assert np.array_equal(lo, ref[2][f].cpu().numpy()) and np.array_equal(ro, ref[3][f].cpu().numpy())
+    assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D, subpixel=True), ref[0][f].cpu().numpy())
