@@ -637,6 +637,9 @@ def run_rank(args):
             "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, {occ_txt}VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
                                    f"{B} frames/GPU/step resident in HBM", "frames_per_step": n_total,
                        "H": H, "W": W, "D": D, "hint_density": P_HINTS, "g_occ": "occlusion_heuristic" if use_occ else None,
+                       "parts": (f"the library runs a call of {B} frames as {-(-B // agg_frames)} consecutive parts of {agg_frames} frames (one round of "
+                                 "the lock-step aggregation kernel each; results do not depend on the split; VPPX_CHUNK=0 keeps whole batches)"
+                                 if 0 < agg_frames < B else None),
                        "cross_step_overlap": (None if (args.no_pipeline or args.graph) else
                                               "front stage of step k+1 (occlusion heuristic, VPP, pad+gray, census) on a second "
                                               "stream under the sum/WTA and post kernels of step k; inputs are resident and declared "
