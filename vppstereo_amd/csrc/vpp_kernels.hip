@@ -454,6 +454,9 @@ __device__ __forceinline__ u8 blend_l_occ_ni(u8 Rd, float c, u8 L)
     return to_u8(__dadd_rn(a, u));
 }
 
+// (Loads inside `for (j < k.C)` loops or behind `if (j >= k.C) break` are serialised by hipcc: one branch + load + wait per
+// channel.  The replay kernels are chains of dependent round trips through memory, so the channels' draws and the pixel's
+// bytes are loaded UNCONDITIONALLY -- a channel that does not exist re-reads channel 0 -- and used afterwards.)
 struct HintGeo {
     int x, d0, d1, d, nk, occ, cnt;
     float g, beta;
@@ -477,15 +480,23 @@ __device__ __forceinline__ u8 draw(const VppK &k, const u8 *rnd, const HintGeo &
 {
     return k.uniform ? rnd[h.base + (u32)j] : rnd[h.base + (u32)j * (u32)h.cnt + (u32)idx];
 }
+__device__ __forceinline__ void draw4(const VppK &k, const u8 *rnd, const HintGeo &h, int idx, u8 (&dv)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) dv[j] = draw(k, rnd, h, j < k.C ? j : 0, idx);
+}
+__device__ __forceinline__ void load_px4(const u8 *px, int C, u8 (&v)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = px[j < C ? j : 0];
+}
 
 // All ops of hint i of row yy (scan order) that touch R pixel (yp, q), for every channel, with
 // xw <= xw_lim.  R[] carries the pixel through the chain.
-__device__ __forceinline__ void r_apply_hint(const VppK &k, int f, int yp, int yy, int i, int q, u8 (&R)[4], const u8 *rnd,
-                                             int xw_lim)
+__device__ __forceinline__ void r_apply_rec(const VppK &k, int f, int yp, int yy, const HintRec rec, int q, u8 (&R)[4], const u8 *rnd,
+                                            int xw_lim)
 {
     const int W = k.W;
-    const size_t rowoff = ((size_t)f * k.H + yy) * W;
-    const HintRec rec = k.rec[rowoff + i];
     HintGeo h;
     decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
     const int yw = yp - yy;
@@ -518,10 +529,12 @@ __device__ __forceinline__ void r_apply_hint(const VppK &k, int f, int yp, int y
         }
         if (!hit0 && !hit1) continue;
         const int idx = k.uniform ? 0 : hint_idx(k, f, yy, h.x, h.g, h.nk, yw, xw);
+        u8 dv[4];
+        draw4(k, rnd, h, idx, dv);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j >= k.C) break;
-            const u8 rv = draw(k, rnd, h, j, idx);
+            const u8 rv = dv[j];
             if (k.interp) {
                 if (hit0) R[j] = blend_r0(rv, cc, R[j], h.beta);
                 if (hit1) R[j] = blend_r1(rv, cc, R[j], h.beta);
@@ -530,6 +543,12 @@ __device__ __forceinline__ void r_apply_hint(const VppK &k, int f, int yp, int y
             }
         }
     }
+}
+
+__device__ __forceinline__ void r_apply_hint(const VppK &k, int f, int yp, int yy, int i, int q, u8 (&R)[4], const u8 *rnd,
+                                             int xw_lim)
+{
+    r_apply_rec(k, f, yp, yy, k.rec[((size_t)f * k.H + yy) * k.W + i], q, R, rnd, xw_lim);
 }
 
 __device__ __forceinline__ bool rng_hit(u32 rg, int q, int W)
@@ -569,8 +588,17 @@ __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim
 #undef CS
             const u32 lim = ((u32)lim_y << 16) | (u32)min(lim_i, 0xFFFF);
             const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
-            for (int i = 0; i < n; i++) { // (a loop, not eight unrolled copies of the replay: the lists are short)
-                const u32 id = i == 0 ? ids[0] : i == 1 ? ids[1] : i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
+            // the records and row bases of the first two entries (most lists hold one or two) are fetched together
+            const int yy0 = (int)(ids[0] >> 16), yy1 = n > 1 ? (int)(ids[1] >> 16) : yy0;
+            const int hi0 = (int)(ids[0] & 0xFFFFu), hi1 = n > 1 ? (int)(ids[1] & 0xFFFFu) : hi0;
+            const HintRec rec0 = k.rec[((size_t)f * H + yy0) * W + hi0], rec1 = k.rec[((size_t)f * H + yy1) * W + hi1];
+            const u32 rb0 = k.row_base[(size_t)f * H + yy0], rb1 = k.row_base[(size_t)f * H + yy1];
+            if (ids[0] > lim) return;
+            r_apply_rec(k, f, yp, yy0, rec0, q, R, rnd_f + rb0, ids[0] == lim ? lim_xw : 0x7FFFFFFF);
+            if (n < 2 || ids[1] > lim) return;
+            r_apply_rec(k, f, yp, yy1, rec1, q, R, rnd_f + rb1, ids[1] == lim ? lim_xw : 0x7FFFFFFF);
+            for (int i = 2; i < n; i++) { // (a loop, not unrolled copies of the replay: the lists are short)
+                const u32 id = i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
                 if (id > lim) break;
                 const int yy = (int)(id >> 16), hi = (int)(id & 0xFFFFu);
                 r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], id == lim ? lim_xw : 0x7FFFFFFF);
@@ -641,8 +669,8 @@ __device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int 
 {
     const int H = k.H;
     u8 *px = k.r + pidx * k.C;
-    u8 R[4] = {0, 0, 0, 0};
-    for (int j = 0; j < k.C; j++) R[j] = px[j];
+    u8 R[4];
+    load_px4(px, k.C, R);
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
 #pragma unroll
     for (int i = 0; i < RLCAP; i++) ids[i] = i < n ? ids[i] : 0xFFFFFFFFu;
@@ -656,10 +684,17 @@ __device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int 
     }
 #undef CS
     // (a loop, not eight unrolled copies of the replay: eight copies of the float64 blends of four channels made this kernel
-    // 75 KB of code -- more than the instruction cache two CUs share)
+    // 75 KB of code -- more than the instruction cache two CUs share.)  The records and row bases of the first two entries --
+    // most lists hold one or two -- are fetched together, ahead of the loop.
+    const int yy0 = (int)(ids[0] >> 16), yy1 = n > 1 ? (int)(ids[1] >> 16) : yy0;
+    const int hi0 = (int)(ids[0] & 0xFFFFu), hi1 = n > 1 ? (int)(ids[1] & 0xFFFFu) : hi0;
+    const HintRec rec0 = k.rec[((size_t)f * H + yy0) * k.W + hi0], rec1 = k.rec[((size_t)f * H + yy1) * k.W + hi1];
+    const u32 rb0 = k.row_base[(size_t)f * H + yy0], rb1 = k.row_base[(size_t)f * H + yy1];
+    r_apply_rec(k, f, yp, yy0, rec0, q, R, rnd_f + rb0, 0x7FFFFFFF);
+    if (n > 1) r_apply_rec(k, f, yp, yy1, rec1, q, R, rnd_f + rb1, 0x7FFFFFFF);
 #pragma unroll 1
-    for (int i = 0; i < n; i++) {
-        const u32 id = i == 0 ? ids[0] : i == 1 ? ids[1] : i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
+    for (int i = 2; i < n; i++) {
+        const u32 id = i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
         const int yy = (int)(id >> 16), hi = (int)(id & 0xFFFFu);
         r_apply_hint(k, f, yp, yy, hi, q, R, rnd_f + k.row_base[(size_t)f * H + yy], 0x7FFFFFFF);
     }
@@ -783,7 +818,11 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
     const int xd0 = xx - h.d0, xd1 = xx - h.d1, xd = xx - h.d;
     if (0 <= xd0 + xw && xd0 + xw <= W - 1) {                       // pyx:104
         if (!h.occ) {                                                 // pyx:106-107
-            for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]);
+            u8 dv[4];
+            draw4(k, rnd, h, idx, dv);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j < k.C) L[j] = blend1(dv[j], k.c, L[j]);
             return true;
         } else if (!k.discard) {                                      // pyx:114-122
             if (defer) {
@@ -797,7 +836,8 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
                 u8 R0[4], R1[4];
                 const u8 *r0p = k.r_src + (((size_t)f * H + yp) * W + q0) * k.C;
                 const u8 *r1p = k.r_src + (((size_t)f * H + yp) * W + q1) * k.C;
-                for (int j = 0; j < 4; j++) { R0[j] = j < k.C ? r0p[j] : 0; R1[j] = j < k.C ? r1p[j] : 0; }
+                load_px4(r0p, k.C, R0); // (unconditional loads; channels that do not exist are never used)
+                load_px4(r1p, k.C, R1);
                 r_chain(k, f, yp, q0, R0, yy, (int)dn.x, xw);
                 if (q1 == q0) {
                     for (int j = 0; j < 4; j++) R1[j] = R0[j];
@@ -810,7 +850,7 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
                 qd = qd < 0 ? qd + W : qd;
                 u8 Rd[4];
                 const u8 *rdp = k.r_src + (((size_t)f * H + yp) * W + qd) * k.C;
-                for (int j = 0; j < 4; j++) Rd[j] = j < k.C ? rdp[j] : 0;
+                load_px4(rdp, k.C, Rd);
                 r_chain(k, f, yp, qd, Rd, yy, (int)dn.x, xw);
                 for (int j = 0; j < k.C; j++) L[j] = blend_l_occ_ni(Rd[j], k.c, L[j]);
             }
@@ -818,7 +858,11 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
         }
         return false;
     }
-    for (int j = 0; j < k.C; j++) L[j] = blend1(draw(k, rnd, h, j, idx), k.c, L[j]); // pyx:123-124
+    u8 dv[4];
+    draw4(k, rnd, h, idx, dv);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j < k.C) L[j] = blend1(dv[j], k.c, L[j]); // pyx:123-124
     return true;
 }
 
@@ -834,13 +878,18 @@ __device__ __forceinline__ bool l_pixel_driven(const VppK &k, int f, int patch_a
 // The replay of one L pixel: the hints of its window in scan order.  Returns false when the pixel was deferred.
 template <int NWIN>
 __device__ __forceinline__ bool l_replay_pixel(const VppK &k, int f, int yp, int xp, unsigned long long mask, const float *gf,
-                                               const u8 *rnd_f, bool may_defer)
+                                               const u8 *rnd_f, bool may_defer, const u8 *L0 = nullptr /* the pixel, already loaded */)
 {
     constexpr int n = (NWIN - 1) / 2;
     const int W = k.W, H = k.H;
     u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
-    u8 L[4] = {0, 0, 0, 0};
-    for (int j = 0; j < k.C; j++) L[j] = px[j];
+    u8 L[4];
+    if (L0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) L[j] = L0[j];
+    } else {
+        load_px4(px, k.C, L);
+    }
     bool touched = false, defer = false;
     while (mask) {
         const int q = __ffsll((long long)mask) - 1;
@@ -850,12 +899,18 @@ __device__ __forceinline__ bool l_replay_pixel(const VppK &k, int f, int yp, int
         touched |= l_apply_hint(k, f, yp, xp, yy, xx, gf[(size_t)yy * W + xx], L, rnd_f, may_defer ? &defer : nullptr);
         if (defer) return false;
     }
-    if (touched)
-        for (int j = 0; j < k.C; j++) px[j] = L[j];
+    if (touched) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (j < k.C) px[j] = L[j];
+    }
     return true;
 }
 
 // the window of hint values around an L pixel as a bit mask in scan order (pyx:78,129)
+// (The loads are UNCONDITIONAL, at clamped coordinates, and the "inside the frame" test selects afterwards: hipcc never
+// speculates a load, so `in ? g[...] : 0` becomes a branch + load + s_waitcnt vmcnt(0) per window position -- nine serialised
+// round trips through memory where one was meant.)
 template <int NWIN>
 __device__ __forceinline__ unsigned long long l_window_mask(const VppK &k, const float *gf, int yp, int xp)
 {
@@ -867,13 +922,19 @@ __device__ __forceinline__ unsigned long long l_window_mask(const VppK &k, const
     for (int wa = 0; wa < NWIN; wa++)
 #pragma unroll
         for (int wb = 0; wb < NWIN; wb++) {
+            const int yc = min(max(yp - n + wa, 0), H - 1);
+            const int xc = min(max(k.direction ? xp - n + wb : xp + n - wb, 0), W - 1);
+            gw[wa * NWIN + wb] = gf[(size_t)yc * W + xc];
+        }
+#pragma unroll
+    for (int wa = 0; wa < NWIN; wa++)
+#pragma unroll
+        for (int wb = 0; wb < NWIN; wb++) {
             const int yy = yp - n + wa;
             const int xx = k.direction ? xp - n + wb : xp + n - wb;
             const bool in = yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
-            gw[wa * NWIN + wb] = in ? gf[(size_t)yy * W + xx] : 0.f;
+            mask |= (in && gw[wa * NWIN + wb] > 0) ? (1ull << (wa * NWIN + wb)) : 0ull;
         }
-#pragma unroll
-    for (int q = 0; q < NP; q++) mask |= (gw[q] > 0) ? (1ull << q) : 0ull;
     return mask;
 }
 
@@ -898,11 +959,13 @@ __global__ void __launch_bounds__(64) apply_l_hint_kernel(VppK k)
         const int hx = k.rec[rowoff + i].x;
         const int yp = y + a - n, xp = hx + b - n; // the patch pixel this thread stands for
         if (yp < 0 || yp > H - 1 || xp < 0 || xp > W - 1) continue;
+        u8 Lpx[4]; // (the pixel's bytes travel with the window's loads)
+        load_px4(k.l + (((size_t)f * H + yp) * W + xp) * k.C, k.C, Lpx);
         const unsigned long long mask = l_window_mask<NWIN>(k, gf, yp, xp);
         // this hint's own bit in that window; a later bit means another hint's thread owns the pixel
         const int my_bit = (2 * n - a) * NWIN + (k.direction ? 2 * n - b : b);
         if ((mask >> my_bit) >> 1) continue;
-        if (!l_replay_pixel<NWIN>(k, f, yp, xp, mask, gf, rnd_f, may_defer)) {
+        if (!l_replay_pixel<NWIN>(k, f, yp, xp, mask, gf, rnd_f, may_defer, Lpx)) {
             const int slot = atomicAdd(k.lwork_cnt, 1);
             k.lwork[2 * (size_t)slot] = (u32)f;
             k.lwork[2 * (size_t)slot + 1] = ((u32)yp << 16) | (u32)xp;
