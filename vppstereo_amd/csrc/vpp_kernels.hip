@@ -13,12 +13,14 @@
 // R pixel reads only that R pixel; a write to an L pixel reads only that L pixel plus, for
 // occluded hints, R "as of that instant".  So every output pixel replays, in key order,
 // exactly the ops that touch it:
-//   1. compact_kernel : per row, hints in scan order + prefix sums of their rand() draws
+//   1. compact_kernel : per row, hints in scan order + prefix sums of their rand() draws + a bitmap of the
+//                       scan positions that hold a hint
 //   2. rowscan_kernel : prefix over rows -> absolute position of every draw in the stream
 //   3. rand_kernel    : glibc TYPE_3 rand() stream generated in parallel by polynomial
 //                       jump-ahead (x_n = x_{n-3} + x_{n-31} mod 2^32 is linear)
-//   4. apply_l_kernel : one thread per L pixel (replays the R sub-chain for occluded hints)
-//   5. apply_r_kernel : one thread per R pixel
+//   4. apply_l_bits_kernel  : L pixels whose window holds a hint (found in the bitmaps, compacted through LDS);
+//      apply_l_heavy_kernel : the ones with an occluded hint (they replay R sub-chains), a pair of lanes each
+//   5. rlist_kernel + apply_r_px_kernel : per-R-pixel hint lists, then the touched R pixels (compacted through LDS)
 // Mixed float32/float64 blend arithmetic follows the C that Cython generates;
 // the library is compiled with -ffp-contract=off and uses explicit _rn intrinsics.
 #include "vppx_internal.h"
@@ -38,6 +40,8 @@ struct HintRec { // 16 bytes, one per hint, row-compacted in scan order
     u32 flags; // bit0 occluded, bits 8..15 patch radius n_k, bits 16..31 cnt (draws per channel, non-uniform)
 };
 
+__host__ __device__ inline int vpp_bits_words(int W) { return (W + 63) / 64 + 2; }
+
 struct VppK {
     int B, H, W, C;
     int n, direction, uniform, discard, interp, use_dist, use_bil;
@@ -51,7 +55,8 @@ struct VppK {
     const float *filled; // may be null
     HintRec *rec;        // [B][H][W]
     u32 *rng;            // [B][H][W] per hint: R-target column range lo | hi<<16 (int16 each)
-    uint4 *dense;        // [B][H][W] at hint pixels: {idx in row, base in row, flags, 0}
+    uint4 *dense;        // [B][H][W] at hint pixels: {idx in row, base in row, flags, bits of the hint value}
+    unsigned long long *bits; // [B][H][vpp_bits_words(W)] which scan positions of a row hold a hint (one zero word before and after)
     int *rcnt;           // [B][H][W] number of hints that touch an R pixel
     u32 *rlist;          // [B][H][W][RLCAP] their (row << 16 | idx in row), unordered
     int *row_count;      // [B][H]
@@ -130,6 +135,8 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
     if (y >= k.H) return;
     const size_t rowoff = ((size_t)f * k.H + y) * k.W;
     u32 run_cnt = 0, run_drw = 0; // wave-uniform running totals of the row
+    unsigned long long *brow = k.bits + ((size_t)f * k.H + y) * vpp_bits_words(k.W);
+    if (lane == 0) brow[0] = 0ull, brow[vpp_bits_words(k.W) - 1] = 0ull;
     for (int p0 = 0; p0 < k.W; p0 += 64) {
         const int p = p0 + lane;
         const int x = k.direction ? p : k.W - 1 - p;
@@ -140,6 +147,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
             is = gv > 0; // NaN and <= 0 are skipped (vpp_core_opt.pyx:81)
         }
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(is);
+        if (lane == 0) brow[1 + (p0 >> 6)] = mk; // bit = scan position: the L side finds the hints of a pixel's window here
         if (mk == 0) continue; // uniform
         int nk = 0;
         u32 cnt = 0, drw = 0;
@@ -166,7 +174,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
             const u32 occ = (k.occ && k.occ[rowoff + x] != 0) ? 1u : 0u;
             r.flags = occ | ((u32)(nk & 0xFF) << 8) | ((cnt & 0xFFFFu) << 16);
             k.rec[rowoff + my_idx] = r;
-            k.dense[rowoff + x] = make_uint4(my_idx, my_base, r.flags, 0u);
+            k.dense[rowoff + x] = make_uint4(my_idx, my_base, r.flags, __float_as_uint(gv));
             // columns of R this hint can touch: [xd0-1-n_k, xd0+n_k] (a negative lo also means the
             // Python-style wraparound write/read of column W-1, SURVEY C-1/C-2)
             int lo = x - (int)floorf(gv) - 1 - nk, hi = x - (int)floorf(gv) + nk;
@@ -491,18 +499,25 @@ __device__ __forceinline__ void load_px4(const u8 *px, int C, u8 (&v)[4])
     for (int j = 0; j < 4; j++) v[j] = px[j < C ? j : 0];
 }
 
-// All ops of hint i of row yy (scan order) that touch R pixel (yp, q), for every channel, with
-// xw <= xw_lim.  R[] carries the pixel through the chain.
-__device__ __forceinline__ void r_apply_rec(const VppK &k, int f, int yp, int yy, const HintRec rec, int q, u8 (&R)[4], const u8 *rnd,
-                                            int xw_lim)
+// All ops of one hint of row yy (scan order) that touch R pixel (yp, q), for every channel, with xw <= xw_lim.
+// R[] carries the pixel through the chain.  Three phases, so that a caller can put the draws of several hints in flight
+// together: r_prep decides which of the (at most two) patch columns act on the pixel and where their draws are, r_draws
+// loads them -- unconditionally: a column that does not act re-reads the first byte of the stream --, r_blend applies them.
+struct RCand {
+    bool on[2], hit0[2], hit1[2];
+    const u8 *dp[2];
+    u32 stride[2];
+    float cc, beta;
+};
+__device__ __forceinline__ void r_prep(const VppK &k, int f, int yp, int yy, const HintRec rec, int q, const u8 *rnd, int xw_lim, RCand &c)
 {
     const int W = k.W;
     HintGeo h;
     decode_hint(rec.x, rec.g, rec.base, rec.flags, h);
     const int yw = yp - yy;
-    if (yw < -h.nk || yw > h.nk) return;
-    if (h.occ && k.discard) return;
-    const float cc = h.occ ? k.c_occ : k.c;
+    const bool row_ok = !(yw < -h.nk || yw > h.nk) && !(h.occ && k.discard);
+    c.cc = h.occ ? k.c_occ : k.c;
+    c.beta = h.beta;
     const int xd0 = h.x - h.d0, xd1 = h.x - h.d1, xd = h.x - h.d;
     const int xw_hi = min(h.nk, xw_lim);
     // The reference walks xw = -n_k .. n_k; only the (at most two) offsets whose target is column q act on this pixel:
@@ -510,15 +525,13 @@ __device__ __forceinline__ void r_apply_rec(const VppK &k, int f, int yp, int yy
     // wraparound write, pyx:113,121).  They are visited in ascending order, as the loop would.
     const int xa = k.interp ? q - xd0 : q - W - xd;
     const int xb = k.interp ? q - xd1 : q - xd;
-#pragma unroll 1
+#pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
         const int xw = s2 == 0 ? xa : xb;
-        if (s2 == 1 && xb == xa) break;
-        if (xw < -h.nk || xw > xw_hi) continue;
         const int xx = h.x + xw;
-        if (xx < 0 || xx > W - 1) continue;                 // pyx:99
-        if (k.use_bil && !gate_pass(k, f, h.g, yp, xx)) continue;
-        if (!(0 <= xd0 + xw && xd0 + xw <= W - 1)) continue; // pyx:104 (else-branch touches L only)
+        bool on = row_ok && !(s2 == 1 && xb == xa) && !(xw < -h.nk || xw > xw_hi) && !(xx < 0 || xx > W - 1); // pyx:99
+        if (k.use_bil && on) on = gate_pass(k, f, h.g, yp, xx);
+        on = on && (0 <= xd0 + xw && xd0 + xw <= W - 1);    // pyx:104 (else-branch touches L only)
         bool hit0, hit1 = false;
         if (k.interp) {
             hit0 = (xd0 + xw == q);
@@ -527,22 +540,64 @@ __device__ __forceinline__ void r_apply_rec(const VppK &k, int f, int yp, int yy
             const int tq = xd + xw;
             hit0 = ((tq < 0 ? tq + W : tq) == q);            // pyx:113,121 (wraparound)
         }
-        if (!hit0 && !hit1) continue;
-        const int idx = k.uniform ? 0 : hint_idx(k, f, yy, h.x, h.g, h.nk, yw, xw);
-        u8 dv[4];
-        draw4(k, rnd, h, idx, dv);
+        on = on && (hit0 || hit1);
+        int idx = 0;
+        if (!k.uniform && (on || !k.use_bil)) idx = hint_idx(k, f, yy, h.x, h.g, h.nk, yw, xw); // (loads only with the bilateral gate)
+        c.on[s2] = on;
+        c.hit0[s2] = hit0;
+        c.hit1[s2] = hit1;
+        c.dp[s2] = on ? rnd + h.base + (u32)idx : k.rnd;
+        c.stride[s2] = on && !k.uniform ? (u32)h.cnt : (on ? 1u : 0u);
+    }
+}
+__device__ __forceinline__ void r_draws(const VppK &k, const RCand &c, u8 (&dv)[2][4])
+{
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) dv[s2][j] = c.dp[s2][(u32)(j < k.C ? j : 0) * c.stride[s2]];
+}
+__device__ __forceinline__ void r_blend(const VppK &k, const RCand &c, const u8 (&dv)[2][4], u8 (&R)[4])
+{
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        if (!c.on[s2]) continue;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j >= k.C) break;
-            const u8 rv = dv[j];
+            const u8 rv = dv[s2][j];
             if (k.interp) {
-                if (hit0) R[j] = blend_r0(rv, cc, R[j], h.beta);
-                if (hit1) R[j] = blend_r1(rv, cc, R[j], h.beta);
+                if (c.hit0[s2]) R[j] = blend_r0(rv, c.cc, R[j], c.beta);
+                if (c.hit1[s2]) R[j] = blend_r1(rv, c.cc, R[j], c.beta);
             } else {
-                R[j] = blend1(rv, cc, R[j]);
+                R[j] = blend1(rv, c.cc, R[j]);
             }
         }
     }
+}
+__device__ __forceinline__ void r_apply_rec(const VppK &k, int f, int yp, int yy, const HintRec rec, int q, u8 (&R)[4], const u8 *rnd,
+                                            int xw_lim)
+{
+    RCand c;
+    u8 dv[2][4];
+    r_prep(k, f, yp, yy, rec, q, rnd, xw_lim, c);
+    r_draws(k, c, dv);
+    r_blend(k, c, dv, R);
+}
+// two hints, the second one only if `two`: all four sets of draws in flight together
+__device__ __forceinline__ void r_apply_rec2(const VppK &k, int f, int yp, int q, u8 (&R)[4], int yy0, const HintRec rec0, const u8 *rnd0,
+                                             int lim0, bool two, int yy1, const HintRec rec1, const u8 *rnd1, int lim1)
+{
+    RCand c0, c1;
+    u8 dv0[2][4], dv1[2][4];
+    r_prep(k, f, yp, yy0, rec0, q, rnd0, lim0, c0);
+    r_prep(k, f, yp, yy1, rec1, q, rnd1, lim1, c1);
+    c1.on[0] = c1.on[0] && two;
+    c1.on[1] = c1.on[1] && two;
+    r_draws(k, c0, dv0);
+    r_draws(k, c1, dv1);
+    r_blend(k, c0, dv0, R);
+    r_blend(k, c1, dv1, R);
 }
 
 __device__ __forceinline__ void r_apply_hint(const VppK &k, int f, int yp, int yy, int i, int q, u8 (&R)[4], const u8 *rnd,
@@ -594,9 +649,10 @@ __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim
             const HintRec rec0 = k.rec[((size_t)f * H + yy0) * W + hi0], rec1 = k.rec[((size_t)f * H + yy1) * W + hi1];
             const u32 rb0 = k.row_base[(size_t)f * H + yy0], rb1 = k.row_base[(size_t)f * H + yy1];
             if (ids[0] > lim) return;
-            r_apply_rec(k, f, yp, yy0, rec0, q, R, rnd_f + rb0, ids[0] == lim ? lim_xw : 0x7FFFFFFF);
-            if (n < 2 || ids[1] > lim) return;
-            r_apply_rec(k, f, yp, yy1, rec1, q, R, rnd_f + rb1, ids[1] == lim ? lim_xw : 0x7FFFFFFF);
+            const bool two = n > 1 && ids[1] <= lim;
+            r_apply_rec2(k, f, yp, q, R, yy0, rec0, rnd_f + rb0, ids[0] == lim ? lim_xw : 0x7FFFFFFF, two, yy1, rec1, rnd_f + rb1,
+                         ids[1] == lim ? lim_xw : 0x7FFFFFFF);
+            if (!two) return;
             for (int i = 2; i < n; i++) { // (a loop, not unrolled copies of the replay: the lists are short)
                 const u32 id = i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
                 if (id > lim) break;
@@ -634,27 +690,45 @@ __global__ void __launch_bounds__(256) rlist_kernel(VppK k)
     const size_t rowoff = ((size_t)f * H + y) * W;
     const int cnt = k.row_count[(size_t)f * H + y];
     const int span = 2 * k.n + 1, tw = 2 * k.n + 2; // rows of the patch, columns of the target range
-    for (int t = threadIdx.x; t < cnt * span * tw; t += 256) {
-        const int i = t / (span * tw), rem = t % (span * tw);
-        const int yw = rem / tw - k.n, tq = rem % tw;
-        const int yp = y + yw;
-        if (yp < 0 || yp > H - 1) continue;
-        const u32 rg = k.rng[rowoff + i];
-        const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
-        const size_t prow = ((size_t)f * H + yp) * W;
-        const u32 id = ((u32)y << 16) | (u32)i;
-        const int q = lo + tq;
-        if (q >= 0 && q <= hi && q <= W - 1) {
-            const int slot = atomicAdd(&k.rcnt[prow + q], 1);
-            if (slot < RLCAP) k.rlist[(prow + q) * RLCAP + slot] = id;
+    const int total = cnt * span * tw;
+    // (four items per thread and round: their range loads, then their atomics, then their stores are in flight together --
+    // a round is three dependent trips through memory whatever the number of items)
+    for (int t0 = threadIdx.x; t0 < total; t0 += 256 * 4) {
+        u32 rgs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rgs[u] = k.rng[rowoff + min(t0 + 256 * u, total - 1) / (span * tw)];
+        size_t at[4], at2[4];
+        bool on[4], on2[4];
+        u32 idv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + 256 * u;
+            const int i = t / (span * tw), rem = t % (span * tw);
+            const int yw = rem / tw - k.n, tq = rem % tw;
+            const int yp = y + yw;
+            const bool ok = t < total && yp >= 0 && yp <= H - 1;
+            const u32 rg = rgs[u];
+            const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
+            const size_t prow = ((size_t)f * H + min(max(yp, 0), H - 1)) * W;
+            idv[u] = ((u32)y << 16) | (u32)i;
+            const int q = lo + tq;
+            on[u] = ok && q >= 0 && q <= hi && q <= W - 1;
+            at[u] = prow + (size_t)min(max(q, 0), W - 1);
+            // Python-style wraparound target, column W-1 (SURVEY C-1/C-2): only the un-interpolated write
+            // r[.., xd+xw] with xd = xd0-1 and xd0+xw == 0 can index -1 (pyx:113,121), i.e. lo < 0 <= hi
+            on2[u] = ok && tq == 0 && !k.interp && lo < 0 && hi >= 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi);
+            at2[u] = prow + W - 1;
         }
-        // Python-style wraparound target, column W-1 (SURVEY C-1/C-2): only the un-interpolated write
-        // r[.., xd+xw] with xd = xd0-1 and xd0+xw == 0 can index -1 (pyx:113,121), i.e. lo < 0 <= hi
-        if (tq == 0 && !k.interp && lo < 0 && hi >= 0) {
-            if (!(W - 1 >= max(lo, 0) && W - 1 <= hi)) {
-                const int slot = atomicAdd(&k.rcnt[prow + W - 1], 1);
-                if (slot < RLCAP) k.rlist[(prow + W - 1) * RLCAP + slot] = id;
-            }
+        int slot[4], slot2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            slot[u] = on[u] ? atomicAdd(&k.rcnt[at[u]], 1) : RLCAP;
+            slot2[u] = on2[u] ? atomicAdd(&k.rcnt[at2[u]], 1) : RLCAP;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (slot[u] < RLCAP) k.rlist[at[u] * RLCAP + slot[u]] = idv[u];
+            if (slot2[u] < RLCAP) k.rlist[at2[u] * RLCAP + slot2[u]] = idv[u];
         }
     }
 }
@@ -690,8 +764,7 @@ __device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int 
     const int hi0 = (int)(ids[0] & 0xFFFFu), hi1 = n > 1 ? (int)(ids[1] & 0xFFFFu) : hi0;
     const HintRec rec0 = k.rec[((size_t)f * H + yy0) * k.W + hi0], rec1 = k.rec[((size_t)f * H + yy1) * k.W + hi1];
     const u32 rb0 = k.row_base[(size_t)f * H + yy0], rb1 = k.row_base[(size_t)f * H + yy1];
-    r_apply_rec(k, f, yp, yy0, rec0, q, R, rnd_f + rb0, 0x7FFFFFFF);
-    if (n > 1) r_apply_rec(k, f, yp, yy1, rec1, q, R, rnd_f + rb1, 0x7FFFFFFF);
+    r_apply_rec2(k, f, yp, q, R, yy0, rec0, rnd_f + rb0, 0x7FFFFFFF, n > 1, yy1, rec1, rnd_f + rb1, 0x7FFFFFFF);
 #pragma unroll 1
     for (int i = 2; i < n; i++) {
         const u32 id = i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
@@ -709,105 +782,79 @@ __device__ __forceinline__ void r_load_list(const VppK &k, size_t pidx, u32 (&id
     ids[4] = b.x; ids[5] = b.y; ids[6] = b.z; ids[7] = b.w;
 }
 
-// Like the L side, two thread mappings: sparse frames walk the (hint, patch row, target column)
-// triples of rlist_kernel again and the thread of the LAST hint (scan order) in the pixel's list
-// replays it (for an overflowed list: the thread of the FIRST listed hint scans the hint rows);
-// dense frames use one thread per pixel.
-__device__ __forceinline__ bool r_pixel_driven(const VppK &k, int f)
+// The same in pixel-driven form with compaction, for every frame: a block reads the list lengths of 256 * PXT
+// consecutive pixels (coalesced), appends the touched ones -- about one in three -- to a list in LDS, and replays them
+// with full waves.  (The hint-driven kernel above spends most of its time finding out, item by item, which thread owns a
+// pixel: four scattered loads per (hint, patch row, column) item, five items per touched pixel.)
+template <int PXT>
+__global__ void __launch_bounds__(256) apply_r_px_kernel(VppK k)
 {
-    const unsigned long long per_hint = (unsigned long long)(2 * k.n + 1) * (2 * k.n + 2);
-    return k.frame_tot[2 * f + 1] * per_hint > (unsigned long long)k.H * k.W;
-}
-
-__global__ void __launch_bounds__(64) apply_r_hint_kernel(VppK k)
-{
-    const int y = blockIdx.x, f = blockIdx.y;
-    const int W = k.W, H = k.H;
-    if (r_pixel_driven(k, f)) return;
-    const size_t rowoff = ((size_t)f * H + y) * W;
-    const int cnt = k.row_count[(size_t)f * H + y];
-    const int span = 2 * k.n + 1, tw = 2 * k.n + 2;
-    for (int t = threadIdx.x; t < cnt * span * tw; t += 64) {
-        const int i = t / (span * tw), rem = t % (span * tw);
-        const int yw = rem / tw - k.n, tq = rem % tw;
-        const int yp = y + yw;
-        if (yp < 0 || yp > H - 1) continue;
-        const u32 rg = k.rng[rowoff + i];
-        const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
-        const size_t prow = ((size_t)f * H + yp) * W;
-        const u32 id = ((u32)y << 16) | (u32)i;
-        // the (up to two) pixels this thread appended to in rlist_kernel
-        int qs[2] = {-1, -1};
-        const int q0 = lo + tq;
-        if (q0 >= 0 && q0 <= hi && q0 <= W - 1) qs[0] = q0;
-        if (tq == 0 && !k.interp && lo < 0 && hi >= 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi)) qs[1] = W - 1;
+    __shared__ unsigned short s_list[256 * PXT];
+    __shared__ int s_total;
+    const int W = k.W, H = k.H, f = blockIdx.y;
+    const size_t npf = (size_t)H * W, i0 = (size_t)blockIdx.x * (256 * PXT);
+    const int t = threadIdx.x, lane = t & 63;
+    if (t == 0) s_total = 0;
+    __syncthreads();
+    int nn[PXT];
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const int q = qs[c];
-            if (q < 0) continue;
-            const size_t pidx = prow + q;
-            const int n = k.rcnt[pidx];
-            u32 ids[RLCAP];
-            r_load_list(k, pidx, ids); // independent of n: both loads are in flight together
-            if (n > RLCAP) { // overflowed list (typically column W-1, the wraparound target of every hint near
-                             // the left border): the thread of the first listed hint scans the hint rows instead
-                if (id != ids[0]) continue;
-                u8 *px = k.r + pidx * k.C;
-                u8 R[4] = {0, 0, 0, 0};
-                for (int j = 0; j < k.C; j++) R[j] = px[j];
-                r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
-                for (int j = 0; j < k.C; j++) px[j] = R[j];
-                continue;
-            }
-            u32 mx = 0;
+    for (int j = 0; j < PXT; j++) {
+        const size_t i = i0 + j * 256 + t;
+        nn[j] = k.rcnt[f * npf + (i < npf ? i : npf - 1)];
+        nn[j] = i < npf ? nn[j] : 0;
+    }
 #pragma unroll
-            for (int e = 0; e < RLCAP; e++) mx = e < n ? max(mx, ids[e]) : mx;
-            if (mx != id) continue;  // a later hint's thread owns the pixel
-            r_replay_list(k, f, yp, q, pidx, n, ids);
+    for (int j = 0; j < PXT; j++) {
+        const bool hit = nn[j] > 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+        if (bal) {
+            const int leader = __builtin_ctzll(bal);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_total, (int)__popcll(bal));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (hit) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (unsigned short)(j * 256 + t);
         }
     }
-}
-
-// (grid: a bounded number of blocks per frame that stride over the frame's (row, 256-column block) pairs: a sparse frame,
-// the common case, costs a few hundred blocks that exit at once instead of one block per 256 pixels)
-__global__ void __launch_bounds__(256) apply_r_kernel(VppK k)
-{
-    const int f = blockIdx.y;
-    const int W = k.W, H = k.H;
-    if (!r_pixel_driven(k, f)) return; // sparse frame: apply_r_hint_kernel did everything
-    const int nxb = (W + 255) / 256;
-    for (int t = blockIdx.x; t < nxb * H; t += gridDim.x) {
-        const int yp = t / nxb, q = (t % nxb) * 256 + threadIdx.x;
-        if (q >= W) continue;
-        const size_t pidx = ((size_t)f * H + yp) * W + q;
+    __syncthreads();
+    const int total = s_total;
+    for (int e = t; e < total; e += 256) {
+        const size_t i = i0 + s_list[e];
+        const int yp = (int)(i / (size_t)W), q = (int)(i % (size_t)W);
+        const size_t pidx = f * npf + i;
         const int n = k.rcnt[pidx];
-        if (n == 0) continue;
+        u32 ids[RLCAP];
+        r_load_list(k, pidx, ids); // independent of n: all three loads are in flight together
         if (n <= RLCAP) {
-            u32 ids[RLCAP];
-            r_load_list(k, pidx, ids);
             r_replay_list(k, f, yp, q, pidx, n, ids);
-            continue;
+        } else { // overflowed list (typically column W-1, the wraparound target of every hint near the left border)
+            u8 *px = k.r + pidx * k.C;
+            u8 R[4] = {0, 0, 0, 0};
+            for (int j = 0; j < k.C; j++) R[j] = px[j];
+            r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
+            for (int j = 0; j < k.C; j++) px[j] = R[j];
         }
-        u8 *px = k.r + pidx * k.C;
-        u8 R[4] = {0, 0, 0, 0};
-        for (int j = 0; j < k.C; j++) R[j] = px[j];
-        r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
-        for (int j = 0; j < k.C; j++) px[j] = R[j];
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// 4. L pixels (must run BEFORE apply_r_kernel: it replays R chains from the original R)
+// 4. L pixels (they replay R chains from the ORIGINAL right image: before apply_r_px_kernel unless the caller kept a copy)
 // ---------------------------------------------------------------------------------------
 // one hint at (yy, xx) acting on L pixel (yp, xp)
 // `defer` != nullptr: the caller cannot afford the occluded-hint branch (it replays R sub-chains: ten times the work of a
 // plain blend, and one such lane holds its whole wave up); instead of taking it, set *defer and return.
-__device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int xp, int yy, int xx, float gv, u8 (&L)[4],
-                                             const u8 *rnd_f, bool *defer = nullptr)
+// (`gv_in` < 0: the hint's value comes with its record in `dense`, one load instead of two dependent ones)
+// LIGHT: the caller always defers (`defer` is not null); the occluded-hint branch and the three R sub-chain replays it
+// inlines -- nine tenths of the code, half of the registers -- are not compiled into such a kernel at all.
+template <bool LIGHT = false>
+// `side` >= 0: the pixel is replayed by a PAIR of lanes (side = lane & 1) that walk it in step; each replays one of the two
+// R sub-chains of an occluded hint and they swap the results, half the dependent trips through memory per hint.
+__device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int xp, int yy, int xx, float gv_in, u8 (&L)[4],
+                                             const u8 *rnd_f, bool *defer = nullptr, int side = -1)
 {
     const int W = k.W, H = k.H;
     const size_t rowoff = ((size_t)f * H + yy) * W;
     const uint4 dn = k.dense[rowoff + xx];
+    const float gv = gv_in < 0 ? __uint_as_float(dn.w) : gv_in;
     HintGeo h;
     decode_hint(xx, gv, dn.y, dn.z, h);
     const int yw = yp - yy, xw = xp - xx;
@@ -825,7 +872,7 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
                 if (j < k.C) L[j] = blend1(dv[j], k.c, L[j]);
             return true;
         } else if (!k.discard) {                                      // pyx:114-122
-            if (defer) {
+            if (LIGHT || defer) {
                 *defer = true;
                 return false;
             }
@@ -834,6 +881,17 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
                 int q1 = xd1 + xw;
                 q1 = q1 < 0 ? q1 + W : q1;                           // unguarded read, pyx:119
                 u8 R0[4], R1[4];
+                if (side >= 0) {
+                    const int qm = side ? q1 : q0;
+                    u8 Rm[4];
+                    load_px4(k.r_src + (((size_t)f * H + yp) * W + qm) * k.C, k.C, Rm);
+                    r_chain(k, f, yp, qm, Rm, yy, (int)dn.x, xw);
+                    const u32 mine = (u32)Rm[0] | ((u32)Rm[1] << 8) | ((u32)Rm[2] << 16) | ((u32)Rm[3] << 24);
+                    const u32 other = (u32)__shfl_xor((int)mine, 1);
+                    const u32 v0 = side ? other : mine, v1 = side ? mine : other;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) R0[j] = (u8)(v0 >> (8 * j)), R1[j] = (u8)(v1 >> (8 * j));
+                } else {
                 const u8 *r0p = k.r_src + (((size_t)f * H + yp) * W + q0) * k.C;
                 const u8 *r1p = k.r_src + (((size_t)f * H + yp) * W + q1) * k.C;
                 load_px4(r0p, k.C, R0); // (unconditional loads; channels that do not exist are never used)
@@ -843,6 +901,7 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
                     for (int j = 0; j < 4; j++) R1[j] = R0[j];
                 } else {
                     r_chain(k, f, yp, q1, R1, yy, (int)dn.x, xw);
+                }
                 }
                 for (int j = 0; j < k.C; j++) L[j] = blend_l_occ(R0[j], R1[j], h.beta, k.c, L[j]);
             } else {
@@ -866,40 +925,83 @@ __device__ __forceinline__ bool l_apply_hint(const VppK &k, int f, int yp, int x
     return true;
 }
 
-// Two thread mappings compute the same per-pixel chain replay.  Sparse frames (hints * patch
-// area <= pixels): one thread per (hint, patch pixel); the thread of the LAST hint (scan order)
-// in the pixel's window owns the pixel and replays every hint of the window.  Dense frames: one
-// thread per pixel.  The choice is per frame, from the hint count left by rowscan_kernel.
-__device__ __forceinline__ bool l_pixel_driven(const VppK &k, int f, int patch_area)
+// What l_apply_hint decides before it needs the draws (no bilateral gate): does the hint blend plainly into the pixel
+// (pyx:106-107,123-124), is it an occluded hint that needs R (pyx:114-122), or neither; and where its draws are.
+struct LPrep {
+    bool plain, occl;
+    const u8 *dp;
+    u32 stride;
+};
+__device__ __forceinline__ void l_prep(const VppK &k, int f, int yp, int xp, int yy, int xx, const uint4 dn, const u8 *rnd, LPrep &o)
 {
-    return k.frame_tot[2 * f + 1] * (unsigned long long)patch_area > (unsigned long long)k.H * k.W;
+    HintGeo h;
+    decode_hint(xx, __uint_as_float(dn.w), dn.y, dn.z, h);
+    const int yw = yp - yy, xw = xp - xx;
+    const bool act = !(yw < -h.nk || yw > h.nk || xw < -h.nk || xw > h.nk);
+    const int idx = k.uniform ? 0 : hint_idx(k, f, yy, xx, h.g, h.nk, yw, xw); // (arithmetic only without the gate)
+    const int t0 = xx - h.d0 + xw;
+    const bool inr = 0 <= t0 && t0 <= k.W - 1;                    // pyx:104
+    o.plain = act && (!inr || !h.occ);
+    o.occl = act && inr && h.occ && !k.discard;
+    o.dp = o.plain ? rnd + h.base + (u32)idx : k.rnd;              // (a hint that does not blend re-reads the first byte of the stream)
+    o.stride = o.plain ? (k.uniform ? 1u : (u32)h.cnt) : 0u;
 }
 
 // The replay of one L pixel: the hints of its window in scan order.  Returns false when the pixel was deferred.
-template <int NWIN>
+template <int NWIN, bool LIGHT = false>
 __device__ __forceinline__ bool l_replay_pixel(const VppK &k, int f, int yp, int xp, unsigned long long mask, const float *gf,
-                                               const u8 *rnd_f, bool may_defer, const u8 *L0 = nullptr /* the pixel, already loaded */)
+                                               const u8 *rnd_f, bool may_defer,
+                                               int side = -1 /* >= 0: one of a pair of lanes on this pixel (l_apply_hint) */)
 {
     constexpr int n = (NWIN - 1) / 2;
     const int W = k.W, H = k.H;
     u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
     u8 L[4];
-    if (L0) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) L[j] = L0[j];
-    } else {
-        load_px4(px, k.C, L);
-    }
+    load_px4(px, k.C, L);
     bool touched = false, defer = false;
+    // The first two hints of the window at once (most windows hold one or two): both records, both row bases and then both
+    // sets of draws are in flight together, two round trips through memory instead of four.  Only where every hint is a
+    // plain blend or a deferral (no occlusion mask, or the pass that defers) and the patch has no bilateral gate.
+    if (!gf && !k.use_bil && (LIGHT || k.occ == nullptr) && mask) {
+        const int q0 = __ffsll((long long)mask) - 1;
+        const unsigned long long m1 = mask & (mask - 1);
+        const bool two = m1 != 0;
+        const int q1 = two ? __ffsll((long long)m1) - 1 : q0;
+        LPrep p0, p1;
+        const int yy0 = yp - n + q0 / NWIN, yy1 = yp - n + q1 / NWIN;
+        const int xx0 = k.direction ? xp - n + q0 % NWIN : xp + n - q0 % NWIN, xx1 = k.direction ? xp - n + q1 % NWIN : xp + n - q1 % NWIN;
+        const uint4 dn0 = k.dense[((size_t)f * H + yy0) * W + xx0], dn1 = k.dense[((size_t)f * H + yy1) * W + xx1];
+        const u32 rb0 = k.row_base[(size_t)f * H + yy0], rb1 = k.row_base[(size_t)f * H + yy1];
+        l_prep(k, f, yp, xp, yy0, xx0, dn0, rnd_f + rb0, p0);
+        l_prep(k, f, yp, xp, yy1, xx1, dn1, rnd_f + rb1, p1);
+        if (p0.occl || (two && p1.occl)) return false; // (only with LIGHT: the pixel goes to the second pass as it is)
+        u8 d0[4], d1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) d0[j] = p0.dp[(u32)(j < k.C ? j : 0) * p0.stride];
+#pragma unroll
+        for (int j = 0; j < 4; j++) d1[j] = p1.dp[(u32)(j < k.C ? j : 0) * p1.stride];
+        if (p0.plain) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j < k.C) L[j] = blend1(d0[j], k.c, L[j]);
+        }
+        if (two && p1.plain) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j < k.C) L[j] = blend1(d1[j], k.c, L[j]);
+        }
+        touched = p0.plain || (two && p1.plain);
+        mask = two ? m1 & (m1 - 1) : 0ull;
+    }
     while (mask) {
         const int q = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         const int yy = yp - n + q / NWIN;
         const int xx = k.direction ? xp - n + q % NWIN : xp + n - q % NWIN;
-        touched |= l_apply_hint(k, f, yp, xp, yy, xx, gf[(size_t)yy * W + xx], L, rnd_f, may_defer ? &defer : nullptr);
+        touched |= l_apply_hint<LIGHT>(k, f, yp, xp, yy, xx, gf ? gf[(size_t)yy * W + xx] : -1.0f, L, rnd_f, (LIGHT || may_defer) ? &defer : nullptr, side);
         if (defer) return false;
     }
-    if (touched) {
+    if (touched && side <= 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (j < k.C) px[j] = L[j];
@@ -938,95 +1040,143 @@ __device__ __forceinline__ unsigned long long l_window_mask(const VppK &k, const
     return mask;
 }
 
-template <int NWIN>
-__global__ void __launch_bounds__(64) apply_l_hint_kernel(VppK k)
-{
-    constexpr int n = (NWIN - 1) / 2, NP = NWIN * NWIN;
-    const int y = blockIdx.x, f = blockIdx.y;
-    const int W = k.W, H = k.H;
-    if (l_pixel_driven(k, f, NP)) return;
-    const size_t rowoff = ((size_t)f * H + y) * W;
-    const int cnt = k.row_count[(size_t)f * H + y];
-    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
-    const float *gf = k.g + (size_t)f * H * W;
-    // With an occlusion mask, a pixel whose window holds an occluded hint replays R sub-chains (pyx:114-122): rare, ten
-    // times the work, and it would hold up the 63 other lanes of its wave.  Such pixels go to a work list and are replayed
-    // by apply_l_heavy_kernel, 64 of them per wave.
-    const bool may_defer = k.occ != nullptr && !k.discard && k.lwork != nullptr;
-    for (int t = threadIdx.x; t < cnt * NP; t += 64) {
-        const int i = t / NP, p = t % NP;
-        const int a = p / NWIN, b = p % NWIN;
-        const int hx = k.rec[rowoff + i].x;
-        const int yp = y + a - n, xp = hx + b - n; // the patch pixel this thread stands for
-        if (yp < 0 || yp > H - 1 || xp < 0 || xp > W - 1) continue;
-        u8 Lpx[4]; // (the pixel's bytes travel with the window's loads)
-        load_px4(k.l + (((size_t)f * H + yp) * W + xp) * k.C, k.C, Lpx);
-        const unsigned long long mask = l_window_mask<NWIN>(k, gf, yp, xp);
-        // this hint's own bit in that window; a later bit means another hint's thread owns the pixel
-        const int my_bit = (2 * n - a) * NWIN + (k.direction ? 2 * n - b : b);
-        if ((mask >> my_bit) >> 1) continue;
-        if (!l_replay_pixel<NWIN>(k, f, yp, xp, mask, gf, rnd_f, may_defer, Lpx)) {
-            const int slot = atomicAdd(k.lwork_cnt, 1);
-            k.lwork[2 * (size_t)slot] = (u32)f;
-            k.lwork[2 * (size_t)slot + 1] = ((u32)yp << 16) | (u32)xp;
-        }
-    }
-}
-
-// second pass of the sparse mapping: the deferred pixels, one thread each (grid-stride over the work list)
+// second pass: the deferred pixels, a pair of lanes each (grid-stride over the work list); the pair replays the pixel in
+// step and splits the two R sub-chains of every occluded hint between its lanes
 template <int NWIN>
 __global__ void __launch_bounds__(64) apply_l_heavy_kernel(VppK k)
 {
     const int cnt = *k.lwork_cnt;
-    for (int e = blockIdx.x * 64 + threadIdx.x; e < cnt; e += gridDim.x * 64) {
+    const int side = threadIdx.x & 1;
+    for (int e = blockIdx.x * 32 + (threadIdx.x >> 1); e < cnt; e += gridDim.x * 32) {
         const int f = (int)k.lwork[2 * (size_t)e];
         const u32 yx = k.lwork[2 * (size_t)e + 1];
         const int yp = (int)(yx >> 16), xp = (int)(yx & 0xFFFFu);
         const float *gf = k.g + (size_t)f * k.H * k.W;
         const unsigned long long mask = l_window_mask<NWIN>(k, gf, yp, xp);
-        (void)l_replay_pixel<NWIN>(k, f, yp, xp, mask, gf, k.rnd + (size_t)f * k.rnd_cap, false);
+        (void)l_replay_pixel<NWIN>(k, f, yp, xp, mask, gf, k.rnd + (size_t)f * k.rnd_cap, false, side);
     }
 }
 
-// NWIN = 2n+1 for n <= 3 (window fits a 64-bit mask): phase A loads the whole window of hint
-// values with independent loads and records, in scan order, which positions hold a hint;
-// phase B visits only those (a wave iterates max-count times, not (2n+1)^2 times).
-// NWIN = 0: generic loop for larger patches.
+// The pixel-driven form of the same replay, for every frame (sparse or dense) with n <= 3.  A block owns ROWS rows x 1024
+// scan positions.  Discovery: the hints of a pixel's window come from the row bitmaps compact_kernel left (bit = scan
+// position, so a window row is NWIN consecutive bits and the mask is in scan order as it stands); the bitmap rows of the
+// block sit in LDS, a pixel costs a few LDS reads and shifts instead of NWIN^2 scattered float loads.  Three pixels in
+// four have an empty window.  Compaction: the others are appended to a list in LDS (one LDS atomic per wave and item), so
+// that the replay -- a few hundred instructions of float64 blends per hint -- runs with full waves instead of a quarter of
+// the lanes; no wave loops over the hints of a row, a single frame has thousands of independent waves.
+#define LB_CW 18 // bitmap words a block needs per row: 16 + one before + one after
+// bits [p - n, p + n] of window row `wa` of the pixel at block row r, chunk c, lane: they start at bit 64 + lane - n of the
+// three 64-bit words c, c + 1, c + 2 of the staged row (c = the word before the chunk's own), i.e. in 32-bit word
+// (64 + lane - n) >> 5 of the six: one two-word LDS read and one v_alignbit
 template <int NWIN>
-__device__ __forceinline__ void apply_l_pixel(const VppK &k, int f, int yp, int xp)
+__device__ __forceinline__ u32 lb_row_bits(const unsigned long long (*s_w)[LB_CW], int row, int c, int lane)
 {
+    constexpr int n = (NWIN - 1) / 2;
+    const int sb = 64 + lane - n;
+    const u32 *w32 = (const u32 *)s_w[row] + 2 * c + (sb >> 5);
+    return __builtin_amdgcn_alignbit(w32[1], w32[0], (u32)(sb & 31)) & ((1u << NWIN) - 1u);
+}
+template <int NWIN>
+__device__ __forceinline__ bool lb_any(const unsigned long long (*s_w)[LB_CW], int r, int c, int lane)
+{
+    u32 any = 0;
+#pragma unroll
+    for (int wa = 0; wa < NWIN; wa++) any |= lb_row_bits<NWIN>(s_w, r + wa, c, lane);
+    return any != 0;
+}
+template <int NWIN>
+__device__ __forceinline__ unsigned long long lb_mask(const unsigned long long (*s_w)[LB_CW], int r, int c, int lane)
+{
+    unsigned long long mask = 0;
+#pragma unroll
+    for (int wa = 0; wa < NWIN; wa++) mask |= (unsigned long long)lb_row_bits<NWIN>(s_w, r + wa, c, lane) << (wa * NWIN);
+    return mask;
+}
+template <int NWIN, int ROWS, bool LIGHT>
+__global__ void __launch_bounds__(256) apply_l_bits_kernel(VppK k)
+{
+    constexpr int n = (NWIN - 1) / 2;
+    __shared__ unsigned long long s_w[ROWS + 2 * n][LB_CW];
+    __shared__ unsigned short s_list[ROWS * 1024], s_dfr[ROWS * 1024];
+    __shared__ int s_total, s_ndfr;
     const int W = k.W, H = k.H;
-    u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
+    const int y0 = blockIdx.y * ROWS, f = blockIdx.z, c0 = blockIdx.x * 16;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nw = vpp_bits_words(W);
+    if (t == 0) s_total = 0, s_ndfr = 0;
+    for (int i = t; i < (ROWS + 2 * n) * LB_CW; i += 256) { // rows outside the frame and words past the row read as empty
+        const int yy = y0 - n + i / LB_CW, gw = c0 + i % LB_CW;
+        const unsigned long long v = k.bits[((size_t)f * H + min(max(yy, 0), H - 1)) * nw + min(gw, nw - 1)];
+        s_w[i / LB_CW][i % LB_CW] = (yy >= 0 && yy <= H - 1 && gw < nw) ? v : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = j * 4 + wv; // chunk of 64 scan positions inside the block
+            const int pp = c * 64 + lane;
+            const bool hit = y0 + r <= H - 1 && c0 * 64 + pp < W && lb_any<NWIN>(s_w, r, c, lane);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            if (bal) {
+                const int leader = __builtin_ctzll(bal);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_total, (int)__popcll(bal));
+                base = __builtin_amdgcn_readlane(base, leader);
+                if (hit) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (unsigned short)(r * 1024 + pp);
+            }
+        }
+    __syncthreads();
+    const int total = s_total;
+    const bool may_defer = k.occ != nullptr && !k.discard && k.lwork != nullptr;
+    const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
+    for (int e = t; e < total; e += 256) {
+        const int id = s_list[e], r = id >> 10, pp = id & 1023;
+        const int yp = y0 + r, p = c0 * 64 + pp;
+        const int xp = k.direction ? p : W - 1 - p;
+        unsigned long long mask = lb_mask<NWIN>(s_w, r, pp >> 6, pp & 63);
+        const bool dfr = !l_replay_pixel<NWIN, LIGHT>(k, f, yp, xp, mask, nullptr, rnd_f, may_defer);
+        // deferred pixels: collected in LDS (in place: slot <= e, and every entry up to e has been consumed), one LDS atomic
+        // per wave; the block then takes its share of the global work list with ONE atomic (atomics on a single address
+        // queue up in one L2 channel: one per wave and round made them the longest part of this kernel)
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(dfr);
+        if (dm) {
+            const int leader = __builtin_ctzll(dm);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_ndfr, (int)__popcll(dm));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (dfr) s_dfr[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(dm >> 32), __builtin_amdgcn_mbcnt_lo((u32)dm, 0u))] = (unsigned short)id;
+        }
+    }
+    if (!may_defer) return; // (uniform)
+    __syncthreads();
+    const int nd = s_ndfr;
+    if (nd == 0) return;
+    if (t == 0) s_total = atomicAdd(k.lwork_cnt, nd);
+    __syncthreads();
+    const int gbase = s_total;
+    for (int e = t; e < nd; e += 256) {
+        const int id = s_dfr[e], p = c0 * 64 + (id & 1023);
+        k.lwork[2 * (size_t)(gbase + e)] = (u32)f;
+        k.lwork[2 * (size_t)(gbase + e) + 1] = ((u32)(y0 + (id >> 10)) << 16) | (u32)(k.direction ? p : W - 1 - p);
+    }
+}
+
+// Patches wider than 7 x 7 (n > 3: the window no longer fits a 64-bit mask): one thread per pixel walks the window's hint
+// values in scan order.  (grid: a bounded number of blocks per frame striding over its (row, 256-column block) pairs)
+__global__ void __launch_bounds__(256) apply_l_wide_kernel(VppK k)
+{
+    const int f = blockIdx.y;
+    const int W = k.W, H = k.H;
     const u8 *rnd_f = k.rnd + (size_t)f * k.rnd_cap;
     const float *gf = k.g + (size_t)f * H * W;
-    bool touched = false;
-    u8 L[4] = {0, 0, 0, 0};
-    if constexpr (NWIN > 0) {
-        constexpr int n = (NWIN - 1) / 2;
-        unsigned long long mask = 0;
-        float gw[NWIN * NWIN];
-#pragma unroll
-        for (int a = 0; a < NWIN; a++)
-#pragma unroll
-            for (int b = 0; b < NWIN; b++) {
-                const int yy = yp - n + a;
-                const int xx = k.direction ? xp - n + b : xp + n - b; // bit order = scan order (pyx:78,129)
-                const bool in = yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
-                gw[a * NWIN + b] = in ? gf[(size_t)yy * W + xx] : 0.f;
-            }
-#pragma unroll
-        for (int i = 0; i < NWIN * NWIN; i++) mask |= (gw[i] > 0) ? (1ull << i) : 0ull;
-        if (mask == 0) return;
-        for (int j = 0; j < k.C; j++) L[j] = px[j];
-        while (mask) {
-            const int i = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int a = i / NWIN, b = i % NWIN;
-            const int yy = yp - n + a;
-            const int xx = k.direction ? xp - n + b : xp + n - b;
-            touched |= l_apply_hint(k, f, yp, xp, yy, xx, gf[(size_t)yy * W + xx], L, rnd_f);
-        }
-    } else {
+    const int nxb = (W + 255) / 256;
+    for (int t = blockIdx.x; t < nxb * H; t += gridDim.x) {
+        const int yp = t / nxb, xp = (t % nxb) * 256 + threadIdx.x;
+        if (xp >= W) continue;
+        u8 *px = k.l + (((size_t)f * H + yp) * W + xp) * k.C;
+        bool touched = false;
+        u8 L[4] = {0, 0, 0, 0};
         for (int j = 0; j < k.C; j++) L[j] = px[j];
         for (int yy = max(0, yp - k.n); yy <= min(H - 1, yp + k.n); yy++) {
             const int xa = max(0, xp - k.n), xb = min(W - 1, xp + k.n);
@@ -1037,20 +1187,8 @@ __device__ __forceinline__ void apply_l_pixel(const VppK &k, int f, int yp, int 
                 touched |= l_apply_hint(k, f, yp, xp, yy, xx, gv, L, rnd_f);
             }
         }
-    }
-    if (touched)
-        for (int j = 0; j < k.C; j++) px[j] = L[j];
-}
-// (grid: a bounded number of blocks per frame striding over its (row, 256-column block) pairs, like apply_r_kernel)
-template <int NWIN>
-__global__ void __launch_bounds__(256) apply_l_kernel(VppK k)
-{
-    const int f = blockIdx.y;
-    if (NWIN > 0 && !l_pixel_driven(k, f, NWIN * NWIN)) return; // sparse frame: apply_l_hint_kernel does it
-    const int nxb = (k.W + 255) / 256;
-    for (int t = blockIdx.x; t < nxb * k.H; t += gridDim.x) {
-        const int yp = t / nxb, xp = (t % nxb) * 256 + threadIdx.x;
-        if (xp < k.W) apply_l_pixel<NWIN>(k, f, yp, xp);
+        if (touched)
+            for (int j = 0; j < k.C; j++) px[j] = L[j];
     }
 }
 
@@ -1633,6 +1771,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     if ((rc = ws_get(ctx, WS_HINT_REC, npx, &k.rec))) return rc;
     if ((rc = ws_get(ctx, WS_HINT_DENSE, npx, &k.dense))) return rc;
     if ((rc = ws_get(ctx, WS_HINT_X, npx, &k.rng))) return rc;
+    if ((rc = ws_get(ctx, WS_HINT_BITS, (size_t)g.B * g.H * vpp_bits_words(g.W), &k.bits))) return rc;
     k.rcnt = nullptr;
     k.lwork = nullptr;
     k.lwork_cnt = nullptr;
@@ -1699,8 +1838,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
                                                                       qoff_for(p.rand_offset), tab, nblk);
     VPPX_CHECK_LAUNCH();
     stage_mark(ctx, ST_VPP_RAND);
-    // the pixel-driven kernels (dense frames): a bounded grid per frame, strided (a sparse frame's blocks exit at once)
-    const int npairs = ((g.W + 255) / 256) * g.H;
+    const int npairs = ((g.W + 255) / 256) * g.H; // (apply_l_wide_kernel: a bounded grid per frame, strided)
     dim3 grid((unsigned)(npairs < 1024 ? npairs : 1024), g.B);
     if ((rc = ws_get(ctx, WS_RCNT, npx, &k.rcnt))) return rc;
     if ((rc = ws_get(ctx, WS_RLIST, npx * RLCAP, &k.rlist))) return rc;
@@ -1712,21 +1850,28 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     const bool split_early = (occ == nullptr) && ctx->stream2 != nullptr;
     const bool split_late = !split_early && r_orig != nullptr && r_orig != r && ctx->stream2 != nullptr;
     const bool split = split_early || split_late;
-    // pixels with an occluded hint in their window: second pass (from 8 frames per call on; for a single frame the extra
-    // launch costs more than the divergence it removes: 0.70 -> 0.77 ms per frame)
-    const bool two_pass = occ != nullptr && !k.discard && k.n <= 3 && g.B >= 8;
+    // pixels with an occluded hint in their window: second pass (at every batch size: for one frame 12 + 25 us against 58
+    // in one pass -- the first pass is a tenth of the code and runs with twice the waves per SIMD)
+    const bool two_pass = occ != nullptr && !k.discard && k.n <= 3;
     if (!two_pass) k.lwork = nullptr; // (rowscan_kernel has zeroed the work-list counter)
     // With two passes the first one never looks at R (it defers every pixel that would): it starts right away on the side
     // stream, next to the list build; only the second pass waits for the lists.
     const bool light_early = two_pass && split_late;
     auto launch_l_hint = [&](hipStream_t st) {
-        switch (k.n) { // sparse frames (each frame picks one of the two mappings on the device)
-        case 0: apply_l_hint_kernel<1><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
-        case 1: apply_l_hint_kernel<3><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
-        case 2: apply_l_hint_kernel<5><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
-        case 3: apply_l_hint_kernel<7><<<dim3(g.H, g.B), 64, 0, st>>>(k); break;
-        default: break;
+        if (k.n > 3) return; // (apply_l_wide_kernel below)
+        // rows per block: four, so that the touched pixels fill whole rounds of the block's replay; one when a call has too few
+        // rows to give every CU a block otherwise.  With two passes the first one has no code for occluded hints at all.
+        const bool r4 = (long long)g.B * g.H >= 4 * 1024;
+        const dim3 bg((unsigned)((g.W + 1023) / 1024), (unsigned)(r4 ? (g.H + 3) / 4 : g.H), (unsigned)g.B);
+#define LB(NW) do { if (two_pass && r4) apply_l_bits_kernel<NW, 4, true><<<bg, 256, 0, st>>>(k); else if (two_pass) apply_l_bits_kernel<NW, 1, true><<<bg, 256, 0, st>>>(k); \
+                    else if (r4) apply_l_bits_kernel<NW, 4, false><<<bg, 256, 0, st>>>(k); else apply_l_bits_kernel<NW, 1, false><<<bg, 256, 0, st>>>(k); } while (0)
+        switch (k.n) {
+        case 0: LB(1); break;
+        case 1: LB(3); break;
+        case 2: LB(5); break;
+        default: LB(7); break;
         }
+#undef LB
     };
     hipStream_t ls = ctx->stream;
     if (split_early || light_early) {
@@ -1751,7 +1896,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         VPPX_CHECK_LAUNCH();
     }
     if (two_pass) {
-        const dim3 hg((unsigned)(g.B * 256 < 16384 ? g.B * 256 : 16384)); // (about one deferred pixel per thread at 3 % hints: the replays are latency chains)
+        const dim3 hg((unsigned)(g.B * 512 < 32768 ? g.B * 512 : 32768)); // (about one deferred pixel per pair of lanes at 3 % hints: the replays are latency chains)
         switch (k.n) {
         case 0: apply_l_heavy_kernel<1><<<hg, 64, 0, ls>>>(k); break;
         case 1: apply_l_heavy_kernel<3><<<hg, 64, 0, ls>>>(k); break;
@@ -1760,18 +1905,14 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         }
         VPPX_CHECK_LAUNCH();
     }
-    switch (k.n) {
-    case 0: apply_l_kernel<1><<<grid, 256, 0, ls>>>(k); break;
-    case 1: apply_l_kernel<3><<<grid, 256, 0, ls>>>(k); break;
-    case 2: apply_l_kernel<5><<<grid, 256, 0, ls>>>(k); break;
-    case 3: apply_l_kernel<7><<<grid, 256, 0, ls>>>(k); break;
-    default: apply_l_kernel<0><<<grid, 256, 0, ls>>>(k); break;
+    if (k.n > 3) apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k);
+    VPPX_CHECK_LAUNCH();
+    {
+        const size_t npf = (size_t)g.H * g.W;
+        if (npf * g.B >= (size_t)4096 * 1024) apply_r_px_kernel<16><<<dim3((unsigned)((npf + 4095) / 4096), g.B), 256, 0, ctx->stream>>>(k);
+        else apply_r_px_kernel<4><<<dim3((unsigned)((npf + 1023) / 1024), g.B), 256, 0, ctx->stream>>>(k);
+        VPPX_CHECK_LAUNCH();
     }
-    VPPX_CHECK_LAUNCH();
-    apply_r_hint_kernel<<<dim3(g.H, g.B), 64, 0, ctx->stream>>>(k);
-    VPPX_CHECK_LAUNCH();
-    apply_r_kernel<<<grid, 256, 0, ctx->stream>>>(k);
-    VPPX_CHECK_LAUNCH();
     if (split) {
         VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
         VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -1870,98 +2011,105 @@ __global__ void __launch_bounds__(256) occ_warp_kernel(const float *__restrict__
         if (0 <= xd && xd <= W - 1) atomicMax(&omap_bits[row + xd], __float_as_int(v)); // positive floats order as ints
     }
 }
-__global__ void __launch_bounds__(256) occ_conf_kernel(const float *__restrict__ omap, u8 *__restrict__ conf, int H, int W, int rx,
-                                                       int ry, double l, double g, double th)
+// weighted_conf (filter.py:115-164) + filter (:168-194) + conf_unwarp (:82-112) in one pass over the HINTS.
+// A valid pixel of omap at x_o holds the value v of exactly one hint, the one at x_o + round(v) (left_warp keeps the
+// maximum of what lands on x_o, and a hint that lands there with that value sits at that column); conf_unwarp sends the
+// pixel's confidence back to x_o + round(v): to the column of the very hint it came from.  So no two pixels of omap
+// unwarp to the same place, the result at a hint's position depends on that hint alone, and the unwarp needs neither
+// an image of winners nor atomics:  out[y, x] = conf of omap[y, x - round(v)] if the hint at x owns that pixel
+// (omap == v) and the filter keeps it, 1 everywhere else (the initial value of conf_unwarp, :101).
+// The confidence in gather form: pixel n = (y, xd) of omap is rejected if some valid centre c with n in c's window is
+// nearer (larger) by more than the weighted distance.  Owners are sparse (the hints, a few per cent): the wave takes
+// them two at a time and tests all window positions of both at once, one per lane and NJ per owner; the loads are
+// unconditional at clamped coordinates (hipcc does not speculate loads: a conditional one costs a branch and a full
+// wait each) so that all 2 NJ are in flight together.
+template <int NJ>
+__global__ void __launch_bounds__(256) occ_test_kernel(const float *__restrict__ hints, const float *__restrict__ omap,
+                                                       u8 *__restrict__ out, int *__restrict__ tmp, int H, int W, int rx,
+                                                       int ry, double l, double g, double th, double th_filter)
 {
-    // weighted_conf (filter.py:115-164), gather form: pixel n is rejected if it is invalid, or if
-    // some valid centre c with n in c's window is nearer (larger) by more than the weighted distance.
-    // Valid pixels are sparse (the warped hints, a few per cent): instead of one lane walking the whole
-    // (2rx+1) x (2ry+2) window of its pixel while 60 lanes idle, the wave takes its valid pixels one after the
-    // other and tests all window positions of that pixel at once, one per lane.
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, f = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const float *om = omap + (size_t)f * H * W;
-    const float dn = x < W ? om[(size_t)y * W + x] : 0.0f;
-    const bool valid = dn > 0;
-    u8 cf = valid ? 0 : 1;
-    const int nyw = 2 * ry + 2, nwin = (2 * rx + 1) * nyw; // centre = (y - yw, x - xw), xw in [-rx,rx], yw in [-ry-1,ry] (:149)
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-    if (nwin <= 256) {
+    const size_t row = ((size_t)f * H + y) * W;
+    const float v = x < W ? hints[row + x] : 0.0f;
+    const int xd = x - (int)rintf(v);
+    const bool lands = v > 0 && 0 <= xd && xd <= W - 1;
+    const float at = om[(size_t)y * W + min(max(xd, 0), W - 1)];
+    const bool owner = lands && at == v;
+    int cf = 0;
+    const int nyw = 2 * ry + 2, nwin = (2 * rx + 1) * nyw; // centre = (y - yw, xd - xw), xw in [-rx,rx], yw in [-ry-1,ry] (:149)
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(owner);
+    if (NJ > 0) {
         // a lane's window positions (lane, lane + 64, ...) and their distance weights do not depend on the pixel under
         // test: worked out once (the integer divisions and four of the five float64 operations of every test)
-        int xwj[4], ywj[4];
-        double wgj[4];
+        int xwj[NJ > 0 ? NJ : 1], ycj[NJ > 0 ? NJ : 1];
+        double wgj[NJ > 0 ? NJ : 1];
+        bool inj[NJ > 0 ? NJ : 1];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
             const int kpos = lane + 64 * j;
             xwj[j] = kpos / nyw - rx;
-            ywj[j] = kpos % nyw - ry - 1;
-            wgj[j] = __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xwj[j])), __dmul_rn(__dsub_rn(1.0, g), (double)abs(ywj[j]))));
-            if (kpos >= nwin) ywj[j] = 0x40000000; // never inside the frame
+            const int yw = kpos % nyw - ry - 1;
+            wgj[j] = __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xwj[j])), __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw))));
+            const int yc = y - yw;
+            inj[j] = kpos < nwin && yc >= 0 && yc <= H - 1;
+            ycj[j] = min(max(yc, 0), H - 1);
         }
-        const int nj = (nwin + 63) >> 6;
         while (todo) {
+            const int s0 = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const bool two = todo != 0;
+            const int s1 = two ? __builtin_ctzll(todo) : s0;
+            todo &= todo - 1; // 0 stays 0
+            const int xs0 = __builtin_amdgcn_readlane(xd, s0), xs1 = __builtin_amdgcn_readlane(xd, s1);
+            const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s0));
+            const float d1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s1));
+            float c0[NJ > 0 ? NJ : 1], c1[NJ > 0 ? NJ : 1];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const float *r = om + (size_t)ycj[j] * W;
+                c0[j] = r[min(max(xs0 - xwj[j], 0), W - 1)];
+                c1[j] = r[min(max(xs1 - xwj[j], 0), W - 1)];
+            }
+            bool h0 = false, h1 = false;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int xc0 = xs0 - xwj[j], xc1 = xs1 - xwj[j];
+                const bool in0 = inj[j] && xc0 >= 0 && xc0 <= W - 1, in1 = inj[j] && xc1 >= 0 && xc1 <= W - 1;
+                if (in0 && c0[j] > 0 && d0 < c0[j]) h0 = h0 || (__dsub_rn((double)__fsub_rn(c0[j], d0), wgj[j]) > th);
+                if (in1 && c1[j] > 0 && d1 < c1[j]) h1 = h1 || (__dsub_rn((double)__fsub_rn(c1[j], d1), wgj[j]) > th);
+            }
+            const bool a0 = __builtin_amdgcn_ballot_w64(h0) != 0, a1 = __builtin_amdgcn_ballot_w64(h1) != 0;
+            if ((a0 && lane == s0) || (a1 && lane == s1)) cf = 1;
+        }
+    } else {
+        while (todo) { // windows of more than 256 positions
             const int src = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const int xs = __builtin_amdgcn_readlane(x, src);
-            const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn), src));
+            const int xs = __builtin_amdgcn_readlane(xd, src);
+            const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
             bool hit = false;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (j >= nj) break; // uniform
-                const int yc = y - ywj[j], xc = xs - xwj[j];
+            for (int kpos = lane; kpos < nwin; kpos += 64) {
+                const int xw = kpos / nyw - rx, yw = kpos % nyw - ry - 1;
+                const int yc = y - yw, xc = xs - xw;
                 if (yc < 0 || yc > H - 1 || xc < 0 || xc > W - 1) continue;
                 const float dc = om[(size_t)yc * W + xc];
-                if (dc > 0 && ds < dc) hit = hit || (__dsub_rn((double)__fsub_rn(dc, ds), wgj[j]) > th);
+                if (dc > 0 && ds < dc) {
+                    const double t = __dsub_rn((double)__fsub_rn(dc, ds),
+                                               __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xw)),
+                                                                      __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw)))));
+                    hit = hit || (t > th);
+                }
             }
             if (__builtin_amdgcn_ballot_w64(hit) != 0 && lane == src) cf = 1;
         }
-        todo = 0;
     }
-    while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int xs = __builtin_amdgcn_readlane(x, src);
-        const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn), src));
-        bool hit = false;
-        for (int kpos = lane; kpos < nwin; kpos += 64) {
-            const int xw = kpos / nyw - rx, yw = kpos % nyw - ry - 1;
-            const int yc = y - yw, xc = xs - xw;
-            if (yc < 0 || yc > H - 1 || xc < 0 || xc > W - 1) continue;
-            const float dc = om[(size_t)yc * W + xc];
-            if (dc > 0 && ds < dc) {
-                const double t = __dsub_rn((double)__fsub_rn(dc, ds),
-                                           __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xw)),
-                                                                  __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw)))));
-                hit = hit || (t > th);
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(hit) != 0 && lane == src) cf = 1;
-    }
-    if (x < W) conf[((size_t)f * H + y) * W + x] = cf;
-}
-__global__ void __launch_bounds__(256) occ_unwarp_kernel(const float *__restrict__ omap, const u8 *__restrict__ conf,
-                                                         int *__restrict__ tmp, int H, int W, double th_filter)
-{
-    // filter (filter.py:168-194) + conf_unwarp (:82-112): last writer in raster order wins
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, f = blockIdx.z;
     if (x >= W) return;
-    const size_t row = ((size_t)f * H + y) * W;
-    const float v = omap[row + x];
-    const u8 cf = conf[row + x];
-    if (v > 0 && !((double)cf > th_filter)) {
-        const int xd = x + (int)rintf(v);
-        if (0 <= xd && xd <= W - 1) atomicMax(&tmp[row + xd], (x << 1) | (int)cf);
-    }
-}
-__global__ void __launch_bounds__(256) occ_final_kernel(const int *__restrict__ tmp, u8 *__restrict__ out, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int t = tmp[i];
-    out[i] = t < 0 ? 1 : (u8)(t & 1); // default 1 (filter.py:101)
+    const bool kept = owner && !((double)cf > th_filter); // filter (:168-194) drops a pixel of omap whose confidence is above the threshold
+    out[row + x] = kept ? (u8)cf : (u8)1;
+    if (tmp) tmp[row + x] = kept ? ((xd << 1) | cf) : -1; // where the value of element [0] sits in omap (occ_dmap_kernel)
 }
 
 // Element [0] of occlusion_heuristic (filter.py:283-292): left_unwarp of the filtered omap (:51-79, last writer in raster
@@ -1997,22 +2145,27 @@ __global__ void __launch_bounds__(256) occ_dmap_kernel(const int *__restrict__ t
 }
 
 int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,
-               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out, float *dmap_out)
+               double th_conf, double th_filter, float *omap, u8 *conf_out, float *dmap_out)
 {
     const size_t n = (size_t)B * H * W;
     dim3 grid((W + 255) / 256, H, B);
     int *tmp = nullptr;
-    int rc = ws_get(ctx, WS_OCC_TMP, n, &tmp);
-    if (rc) return rc;
+    if (dmap_out) {
+        int rc = ws_get(ctx, WS_OCC_TMP, n, &tmp);
+        if (rc) return rc;
+    }
     VPPX_HIP(hipMemsetAsync(omap, 0, n * sizeof(float), ctx->stream));
     occ_warp_kernel<<<grid, 256, 0, ctx->stream>>>(hints, (int *)omap, H, W);
     VPPX_CHECK_LAUNCH();
-    occ_conf_kernel<<<grid, 256, 0, ctx->stream>>>(omap, conf, H, W, rx / 2, ry / 2, l, g, th_conf);
-    VPPX_CHECK_LAUNCH();
-    VPPX_HIP(hipMemsetAsync(tmp, 0xFF, n * sizeof(int), ctx->stream));
-    occ_unwarp_kernel<<<grid, 256, 0, ctx->stream>>>(omap, conf, tmp, H, W, th_filter);
-    VPPX_CHECK_LAUNCH();
-    occ_final_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(tmp, conf_out, n);
+    rx /= 2, ry /= 2; // filter.py:142-143
+    const long long nwin = (2LL * rx + 1) * (2LL * ry + 2);
+#define OCC_TEST(NJ) occ_test_kernel<NJ><<<grid, 256, 0, ctx->stream>>>(hints, omap, conf_out, tmp, H, W, rx, ry, l, g, th_conf, th_filter)
+    if (nwin <= 64) OCC_TEST(1);
+    else if (nwin <= 128) OCC_TEST(2);
+    else if (nwin <= 192) OCC_TEST(3);
+    else if (nwin <= 256) OCC_TEST(4);
+    else OCC_TEST(0);
+#undef OCC_TEST
     VPPX_CHECK_LAUNCH();
     if (dmap_out) {
         occ_dmap_kernel<<<grid, 256, 0, ctx->stream>>>(tmp, omap, dmap_out, H, W);

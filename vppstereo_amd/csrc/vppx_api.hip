@@ -1223,10 +1223,9 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
     if ((piped || !l_vpp) && (rc = ws_get(ctx, WS_VPP_L, nb, &l_vpp))) return rc;
     if ((piped || !r_vpp) && (rc = ws_get(ctx, WS_VPP_R, nb, &r_vpp))) return rc;
     float *omap = nullptr;
-    u8 *conf_scr = nullptr, *conf = conf_out;
+    u8 *conf = conf_out;
     if (op) {
         if ((rc = ws_get(ctx, WS_OCC_OMAP, np, &omap))) return rc;
-        if ((rc = ws_get(ctx, WS_OCC_CONF, np, &conf_scr))) return rc;
         if ((piped || !conf_out) && (rc = ws_get(ctx, WS_OCC_OUT, np, &conf))) return rc;
     }
     FrontGuard guard{ctx};
@@ -1240,7 +1239,7 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
     }
     stage_begin(ctx);
     if (op) { // test.py:154: g_occ = occlusion_heuristic(hints)[1]
-        if ((rc = occ_launch(ctx, B, H, W, g, op->rx, op->ry, op->l, op->g, op->th_conf, op->th_filter, omap, conf_scr, conf))) return rc;
+        if ((rc = occ_launch(ctx, B, H, W, g, op->rx, op->ry, op->l, op->g, op->th_conf, op->th_filter, omap, conf))) return rc;
         stage_mark(ctx, ST_OCC);
         g_occ = conf;
     }
@@ -1579,10 +1578,8 @@ extern "C" int vppx_occlusion_heuristic_full_dev(vppx_ctx *ctx, int B, int H, in
     if (!hints || !conf_out || B <= 0 || H <= 0 || W <= 0) { vppx_set_error("vppx_occlusion_heuristic: bad arguments"); return VPPX_E_INVALID_ARG; }
     const size_t n = (size_t)B * H * W;
     float *omap;
-    u8 *conf;
     if ((rc = ws_get(ctx, WS_OCC_OMAP, n, &omap))) return rc;
-    if ((rc = ws_get(ctx, WS_OCC_CONF, n, &conf))) return rc;
-    return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf, conf_out, dmap_out);
+    return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf_out, dmap_out);
 }
 
 // Cross-call pipelining of vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev (contract: include/vppx.h).  Off by default.

@@ -43,6 +43,7 @@ enum WsSlot {
     WS_HINT_X = 0,   // compacted hint rows
     WS_HINT_REC,
     WS_HINT_DENSE,
+    WS_HINT_BITS,    // per row: which scan positions hold a hint (u64 words)
     WS_RCNT,
     WS_FILLED_G,
     WS_GRAY_CTX,
@@ -91,7 +92,6 @@ enum WsSlot {
     WS_STAGE_E,
     WS_STAGE_F,
     WS_OCC_OMAP,
-    WS_OCC_CONF,
     WS_OCC_OUT,       // the mask of the fused occlusion + VPP + rSGM call (library-owned: the front stage never writes caller memory)
     WS_OCC_TMP,       // unwarp scratch of the occlusion heuristic (its own slot: with vppx_set_pipeline it runs next to the previous call's speckle filter, which owns WS_LABEL)
     WS_NHINTS,
@@ -327,4 +327,4 @@ int handoff_png_decode(vppx_ctx *ctx, int n_files, const u8 *blob_dev, const lon
 
 // occ_kernels (in vpp_kernels.hip)
 int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, int ry, double l, double g,
-               double th_conf, double th_filter, float *omap, u8 *conf, u8 *conf_out, float *dmap_out = nullptr);
+               double th_conf, double th_filter, float *omap, u8 *conf_out, float *dmap_out = nullptr);
