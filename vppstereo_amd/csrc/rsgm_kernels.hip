@@ -3241,41 +3241,58 @@ int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const f
 }
 
 // Fused median3x3 -> _linear_interpolate -> clip for the left and the right view (rsgm.py:145-151,
-// 173-179): one block per row; the row's medians go to LDS, the interpolation of every hole pixel
-// reads them from there.  (Same arithmetic as the two stand-alone kernels above, which the stage
-// API keeps using.)
+// 173-179): one block per row; the row's medians go to LDS, together with a bitmap of the valid (> 0) ones; a hole pixel
+// finds its nearest valid neighbours (at most 13 to the left, then as far to the right as the reference's window of 14
+// allows) with two bit scans of a 27-bit window of that bitmap instead of two loops over LDS -- the pad columns make every
+// row end in holes, and one hole keeps its whole wave in those loops.  (Same arithmetic as the two stand-alone kernels
+// above, which the stage API keeps using.)
 __global__ void __launch_bounds__(256) median_interp_clip_kernel(ImgSet io, int B, int Hp, int Wp)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_med[]; // [Wp]
+    extern __shared__ __attribute__((aligned(16))) float s_med[]; // [Wp] medians, then the bitmap: [Wp / 64 + 3] 64-bit words
+    const int nwords = (Wp + 63) / 64;
+    unsigned long long *s_bits = (unsigned long long *)(s_med + ((Wp + 1) & ~1)); // word 0 and the last one stay empty
     const int y = blockIdx.x;
     const int set = blockIdx.y / B, f = blockIdx.y % B;
+    const int lane = threadIdx.x & 63;
     const float *s = (const float *)(set == 0 ? io.src[0] : io.src[1]) + (size_t)f * Hp * Wp;
     float *dst = (float *)(set == 0 ? io.dst[0] : io.dst[1]) + ((size_t)f * Hp + y) * Wp;
-    for (int x = threadIdx.x; x < Wp; x += 256) {
-        float out;
-        if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
-            out = s[(size_t)y * Wp + x];
-        } else {
-            float v[9];
+    if (threadIdx.x == 0) s_bits[0] = 0ull, s_bits[nwords + 1] = 0ull;
+    for (int xb = threadIdx.x & ~63; xb < Wp; xb += 256) { // (whole waves: the ballot below wants every lane)
+        const int x = xb + lane;
+        float out = 0.0f;
+        if (x < Wp) {
+            if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
+                out = s[(size_t)y * Wp + x];
+            } else {
+                float v[9];
 #pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
+                for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-                for (int dx = -1; dx <= 1; dx++) v[(dy + 1) * 3 + dx + 1] = s[(size_t)(y + dy) * Wp + x + dx];
-            out = median9(v);
+                    for (int dx = -1; dx <= 1; dx++) v[(dy + 1) * 3 + dx + 1] = s[(size_t)(y + dy) * Wp + x + dx];
+                out = median9(v);
+            }
+            s_med[x] = out;
         }
-        s_med[x] = out;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(x < Wp && out > 0);
+        if (lane == 0) s_bits[1 + (xb >> 6)] = bal;
     }
     __syncthreads();
     const float *row = s_med;
+    const u32 *b32 = (const u32 *)s_bits;
     for (int x = threadIdx.x; x < Wp; x += 256) {
         float v = row[x];
         if (v <= 0) {
+            // bit j of w: is pixel x - 13 + j valid (j = 0..26; pixels outside the row read as invalid)
+            const int sb = 64 + x - 13;
+            const u32 w = __builtin_amdgcn_alignbit(b32[(sb >> 5) + 1], b32[sb >> 5], (u32)(sb & 31)) & 0x7FFFFFFu;
+            const u32 wl = w & 0x1FFFu; // x - 13 .. x - 1
             int xl = -1, xr = -1;
-            for (int k = 1; k <= 13; k++)
-                if (x - k >= 0 && row[x - k] > 0) { xl = x - k; break; }
-            if (xl >= 0) {
-                for (int k = 1; k <= 14 - (x - xl); k++)
-                    if (x + k < Wp && row[x + k] > 0) { xr = x + k; break; }
+            if (wl) {
+                xl = x - 13 + (31 - __builtin_clz(wl));
+                // x + k with 1 <= k <= 14 - (x - xl): bits 14 .. 27 - (x - xl)
+                const int top = 27 - (x - xl);
+                const u32 wr = (w >> 14) & ((1u << (top - 13)) - 1u);
+                if (wr) xr = x + 1 + __builtin_ctz(wr);
             }
             if (xl >= 0 && xr >= 0) {
                 const double n_left = (double)row[xl], n_right = (double)row[xr];
@@ -3297,7 +3314,8 @@ int rsgm_launch_median_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const f
 {
     ImgSet io;
     io.src[0] = src_l; io.dst[0] = dst_l; io.src[1] = src_r; io.dst[1] = dst_r; io.src[2] = nullptr; io.dst[2] = nullptr;
-    median_interp_clip_kernel<<<dim3(Hp, 2 * B), 256, (size_t)Wp * sizeof(float), ctx->stream>>>(io, B, Hp, Wp);
+    const size_t lds = (size_t)((Wp + 1) & ~1) * sizeof(float) + (size_t)((Wp + 63) / 64 + 3) * sizeof(unsigned long long);
+    median_interp_clip_kernel<<<dim3(Hp, 2 * B), 256, lds, ctx->stream>>>(io, B, Hp, Wp);
     VPPX_CHECK_LAUNCH();
     return 0;
 }
@@ -3386,42 +3404,54 @@ __device__ __forceinline__ void lds_union(int *lab, int a, int b)
 }
 
 __global__ void __launch_bounds__(256) speckle_tile_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
-                                                           float *__restrict__ fdc, u8 *__restrict__ fd8, int *__restrict__ label,
-                                                           int *__restrict__ size, int H, int W, int Hp, int Wp, int pad_t, int pad_l,
-                                                           int new_val, int max_diff)
+                                                           u8 *__restrict__ fd8, int *__restrict__ label, int *__restrict__ size,
+                                                           int *__restrict__ roots, int *__restrict__ nroots, int H, int W, int Hp,
+                                                           int Wp, int pad_t, int pad_l, int new_val, int max_diff)
 {
     __shared__ int s_lab[SPK_TH * SPK_TW];
     __shared__ int s_cnt[SPK_TH * SPK_TW];
     __shared__ u8 s_val[SPK_TH * SPK_TW];
+    __shared__ int s_nroot;
+    if (threadIdx.x == 0) s_nroot = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tx0 = blockIdx.x * SPK_TW, ty0 = blockIdx.y * SPK_TH, f = blockIdx.z;
     const int x = tx0 + lane;
     constexpr int RPW = SPK_TH / 4; // tile rows per wave
     int vv[RPW], ss[RPW];
+    // (the wave's eight left disparities, then the eight right ones they point at: unconditional loads at clamped
+    // positions, two round trips through memory instead of sixteen -- hipcc serialises a load behind a branch)
+    float dvs[RPW], rvs[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int y = min(ty0 + wv * RPW + k, H - 1);
+        dvs[k] = dl[((size_t)f * Hp + y + pad_t) * Wp + pad_l + min(x, W - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int y = min(ty0 + wv * RPW + k, H - 1);
+        const int d = dvs[k] > 0 ? (int)rintf(dvs[k]) : 0; // round half to even (numba round)
+        rvs[k] = dr[((size_t)f * Hp + y + pad_t) * Wp + pad_l + min(max(min(x, W - 1) - d, 0), W - 1)];
+    }
 #pragma unroll
     for (int k = 0; k < RPW; k++) {
         const int r = wv * RPW + k, y = ty0 + r;
         int v = new_val;
         if (x < W && y < H) {
             // crop + left/right check (rsgm.py:230-248, 275-283)
-            const float *rl = dl + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
-            const float *rr = dr + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
-            const float dv = rl[x];
+            const float dv = dvs[k];
             float keep = dv;
             if (dv > 0) {
-                const int d = (int)rintf(dv); // round half to even (numba round)
+                const int d = (int)rintf(dv);
                 const int xd = x - d;
                 if (0 <= xd && xd <= W - 1) {
-                    const float rv = rr[xd];
+                    const float rv = rvs[k];
                     if (rv > 0 && fabsf(__fsub_rn(dv, rv)) > 1.0f) keep = 0; // mask 128
                 } else {
                     keep = 0; // mask 128
                 }
             }
-            const size_t o = ((size_t)f * H + y) * W + x;
-            fdc[o] = dv;
             const u8 k8 = (u8)keep; // astype(np.uint8): truncation, values in [0,256)
-            fd8[o] = k8;
+            fd8[((size_t)f * H + y) * W + x] = k8;
             v = k8;
         }
         const int vprev = __shfl_up(v, 1);
@@ -3466,16 +3496,31 @@ __global__ void __launch_bounds__(256) speckle_tile_kernel(const float *__restri
         atomicAdd(&s_cnt[lds_find(s_lab, r * SPK_TW + ss[k])], lane - ss[k] + 1);
     }
     __syncthreads();
+    // labels for every pixel; the size only AT the local roots, which also go on the tile's root list (speckle_total_kernel
+    // walks those lists instead of a whole image of mostly-zero sizes)
+    const int tile = (f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    int *rl = roots + (size_t)tile * (SPK_TW * SPK_TH);
 #pragma unroll
     for (int k = 0; k < RPW; k++) {
         const int r = wv * RPW + k, y = ty0 + r, p = r * SPK_TW + lane;
-        if (x >= W || y >= H) continue;
+        const bool inside = x < W && y < H;
         const int v = vv[k];
         const int root = v != new_val ? lds_find(s_lab, r * SPK_TW + ss[k]) : p;
-        const size_t o = ((size_t)f * H + y) * W + x;
-        label[o] = (ty0 + root / SPK_TW) * W + tx0 + root % SPK_TW;
-        size[o] = (v != new_val && root == p) ? s_cnt[p] : 0;
+        const size_t o = ((size_t)f * H + min(y, H - 1)) * W + min(x, W - 1);
+        const bool is_root = inside && v != new_val && root == p;
+        if (inside) label[o] = (ty0 + root / SPK_TW) * W + tx0 + root % SPK_TW;
+        if (is_root) size[o] = s_cnt[p];
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(is_root);
+        if (bal) {
+            const int leader = __builtin_ctzll(bal);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_nroot, (int)__popcll(bal));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (is_root) rl[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = y * W + x;
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) nroots[tile] = s_nroot;
 }
 
 __global__ void __launch_bounds__(256) speckle_border_kernel(const u8 *__restrict__ img, int *__restrict__ label, int H, int W,
@@ -3510,67 +3555,91 @@ __global__ void __launch_bounds__(256) speckle_border_kernel(const u8 *__restric
     uf_union(lb, lb[ia], lb[ib]);
 }
 
-// every tile-local root adds its component's size to its global root (all unions are done: roots are final)
-__global__ void __launch_bounds__(256) speckle_total_kernel(int *__restrict__ label, int *__restrict__ size, size_t npix_frame, int nframes)
+// every tile-local root adds its component's size to its global root (all unions are done: roots are final); one wave per
+// tile walks the tile's root list
+__global__ void __launch_bounds__(64) speckle_total_kernel(int *__restrict__ label, int *__restrict__ size, const int *__restrict__ roots,
+                                                           const int *__restrict__ nroots, size_t npix_frame, int tiles_per_frame)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix_frame * nframes) return;
-    const int sz = size[i];
-    if (sz <= 0) return;
-    const size_t base = i / npix_frame * npix_frame;
+    const int tile = blockIdx.x;
+    const size_t base = (size_t)(tile / tiles_per_frame) * npix_frame;
     int *lb = label + base;
-    const int me = (int)(i - base);
-    int c = me, p = lb[c];
-    while (p != c) { // path halving (shortcuts to an ancestor are benign under concurrency)
-        const int gp = lb[p];
-        if (gp != p) lb[c] = gp;
-        c = gp;
-        p = lb[c];
-    }
-    if (c != me) {
-        lb[me] = c;
-        atomicAdd(&size[base + c], sz);
-    }
-}
-
-__global__ void __launch_bounds__(256) speckle_apply_kernel(const u8 *__restrict__ fd8, const int *__restrict__ label,
-                                                             const int *__restrict__ size, const float *__restrict__ fdc,
-                                                             float *__restrict__ out, size_t npix_frame, int nframes, int new_val,
-                                                             int max_size, int subpixel)
-{
-    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (o >= npix_frame * nframes) return;
-    int v = fd8[o];
-    if (v != new_val) {
-        const size_t base = o / npix_frame * npix_frame;
-        const int *lb = label + base;
-        int r = lb[o - base], pr = lb[r];
-        while (pr != r) {
-            r = pr;
-            pr = lb[r];
+    const int n = nroots[tile];
+    const int *rl = roots + (size_t)tile * (SPK_TW * SPK_TH);
+    for (int e = threadIdx.x; e < n; e += 64) {
+        const int me = rl[e];
+        const int sz = size[base + me];
+        int c = me, p = lb[c];
+        while (p != c) { // path halving (shortcuts to an ancestor are benign under concurrency)
+            const int gp = lb[p];
+            if (gp != p) lb[c] = gp;
+            c = gp;
+            p = lb[c];
         }
-        if (size[base + r] <= max_size) v = new_val;
+        if (c != me) {
+            lb[me] = c;
+            atomicAdd(&size[base + c], sz);
+        }
     }
-    float fv = (float)v;                       // rsgm.py:286
-    if (subpixel && fv != 0.0f) fv = fdc[o];   // rsgm.py:289-290
-    out[o] = fv;
 }
 
-// _interpolate_background rows (rsgm.py:189-214).  Fills only touch invalid (<= 0) pixels and
-// read only originally valid ones, so per pixel: nearest valid to the left (xl) and to the
-// right (xr) of the ORIGINAL row; both -> min(v[xl], v[xr]); only one -> that one (border
-// extension); none -> unchanged.  Each thread owns a contiguous segment of the row; the nearest
-// valid index outside the segment comes from one wave-level max/min scan (+ 4 wave carries).
+// speckle filter result (components of at most maxSpeckleSize pixels become newVal, float32 again, sub-pixel values restored,
+// rsgm.py:285-290) fused with the row pass of _interpolate_background (rsgm.py:189-214): one block per row, the filtered row
+// only ever exists in LDS.  Fills only touch invalid (<= 0) pixels and read only originally valid ones, so per pixel: nearest
+// valid to the left (xl) and to the right (xr) of the ORIGINAL row; both -> min(v[xl], v[xr]); only one -> that one (border
+// extension); none -> unchanged.  Each thread owns a contiguous segment of the row; the nearest valid index outside the
+// segment comes from one wave-level max/min scan (+ 4 wave carries).  A row with one valid pixel ends up valid everywhere;
+// row_any[] says which rows are, for the column pass.
 template <int SEGMAX> // pixels per thread: 8 covers W <= 2048, 32 covers W <= 8192
-__global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__ dm, int H, int W)
+__global__ void __launch_bounds__(256) speckle_apply_rows_kernel(const u8 *__restrict__ fd8, const int *__restrict__ label,
+                                                                  const int *__restrict__ size, const float *__restrict__ dl_pad,
+                                                                  float *__restrict__ out, u8 *__restrict__ row_any, int H, int W, int Hp,
+                                                                  int Wp, int pad_t, int pad_l, int new_val, int max_size, int subpixel)
 {
-    extern __shared__ __attribute__((aligned(16))) float sh_f[]; // [W] original row, [W] result
+    extern __shared__ __attribute__((aligned(16))) float sh_f[]; // [W] filtered row, [W] result
     __shared__ int s_l[4], s_r[4];
     float *val = sh_f, *res = sh_f + W;
     const int y = blockIdx.x, f = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float *g = dm + ((size_t)f * H + y) * W;
-    for (int x = threadIdx.x; x < W; x += 256) val[x] = g[x];
+    const size_t base = (size_t)f * H * W, rowo = base + (size_t)y * W;
+    const int *lb = label + base;
+    const float *dlr = dl_pad + ((size_t)f * Hp + y + pad_t) * Wp + pad_l;
+    float *g = out + rowo;
+    // (four pixels per thread and round, every level of the label chase for all four before the next one: the loads are
+    // unconditional -- at clamped positions past the end of the row -- so that they are in flight together)
+    for (int xb = threadIdx.x; xb < W; xb += 4 * 256) {
+        int v[4], r1[4], r2[4];
+        float sub[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = min(xb + 256 * u, W - 1);
+            v[u] = fd8[rowo + x];
+            r1[u] = label[rowo + x];
+            sub[u] = dlr[x];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) r2[u] = lb[r1[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int r = r1[u], pr = r2[u];
+            while (pr != r) {
+                r = pr;
+                pr = lb[r];
+            }
+            r1[u] = r;
+        }
+        int sz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sz[u] = size[base + r1[u]]; // (meaningless where v == new_val: not used there)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = xb + 256 * u;
+            int vv = v[u];
+            if (vv != new_val && sz[u] <= max_size) vv = new_val;
+            float fv = (float)vv;                      // rsgm.py:286
+            if (subpixel && fv != 0.0f) fv = sub[u];   // rsgm.py:289-290
+            if (x < W) val[x] = fv;
+        }
+    }
     __syncthreads();
     const int SEG = (W + 255) / 256; // <= SEGMAX
     const int x0 = threadIdx.x * SEG;
@@ -3592,6 +3661,7 @@ __global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__
     if (lane == 63) s_l[wv] = sl;
     if (lane == 0) s_r[wv] = sr;
     __syncthreads();
+    if (threadIdx.x == 0) row_any[(size_t)f * H + y] = max(max(s_l[0], s_l[1]), max(s_l[2], s_l[3])) >= 0 ? 1 : 0;
     int cl = __shfl_up(sl, 1), cr = __shfl_down(sr, 1);
     if (lane == 0) cl = -1;
     if (lane == 63) cr = 0x7FFFFFFF;
@@ -3625,37 +3695,32 @@ __global__ void __launch_bounds__(256) interp_bg_rows_kernel(float *__restrict__
         res[x] = v;
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256)
-        if (!(val[x] > 0)) g[x] = res[x];
+    for (int x = threadIdx.x; x < W; x += 256) g[x] = res[x]; // (res == val where val is valid)
 }
-// columns (rsgm.py:216-227): per column, rows above the first valid row take its value, rows
-// below the last valid row take that one's.  Block = 64 columns x 4 row-lanes.
-#define BGC_RL 16 // row lanes per column (a block is 64 columns wide: few blocks per frame, so each gets many rows in flight)
-__global__ void __launch_bounds__(64 * BGC_RL) interp_bg_cols_kernel(float *__restrict__ dm, int H, int W)
+// columns (rsgm.py:216-227): per column, rows above the first valid row take its value, rows below the last valid row take
+// that one's.  After the row pass a row is valid everywhere or nowhere, so the first and the last valid row are the same
+// for every column: the rows above the first non-empty row become copies of it, the rows below the last one copies of
+// that (usually there are none).  One block per frame.
+__global__ void __launch_bounds__(256) interp_bg_edge_rows_kernel(float *__restrict__ dm, const u8 *__restrict__ row_any, int H, int W)
 {
-    __shared__ int s_first[BGC_RL][64], s_last[BGC_RL][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int u = blockIdx.x * 64 + cx;
-    const int f = blockIdx.y;
+    __shared__ int s_first[4], s_last[4];
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *g = dm + (size_t)f * H * W;
     int first = 0x7FFFFFFF, last = -1;
-    if (u < W)
-        for (int v = ry; v < H; v += BGC_RL)
-            if (g[(size_t)v * W + u] > 0) { first = min(first, v); last = max(last, v); }
-    s_first[ry][cx] = first;
-    s_last[ry][cx] = last;
-    __syncthreads();
-    first = 0x7FFFFFFF;
-    last = -1;
+    for (int v = threadIdx.x; v < H; v += 256)
+        if (row_any[(size_t)f * H + v]) { first = min(first, v); last = max(last, v); }
 #pragma unroll
-    for (int k = 0; k < BGC_RL; k++) {
-        first = min(first, s_first[k][cx]);
-        last = max(last, s_last[k][cx]);
+    for (int off = 32; off >= 1; off >>= 1) {
+        first = min(first, __shfl_xor(first, off));
+        last = max(last, __shfl_xor(last, off));
     }
-    if (u >= W || last < 0) return;
-    const float fv = g[(size_t)first * W + u], lv = g[(size_t)last * W + u];
-    for (int v = ry; v < first; v += BGC_RL) g[(size_t)v * W + u] = fv;
-    for (int v = last + 1 + ry; v < H; v += BGC_RL) g[(size_t)v * W + u] = lv;
+    if (lane == 0) s_first[wv] = first, s_last[wv] = last;
+    __syncthreads();
+    first = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
+    last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    if (last < 0) return;
+    for (size_t i = threadIdx.x; i < (size_t)first * W; i += 256) g[i] = g[(size_t)first * W + i % W];
+    for (size_t i = (size_t)(last + 1) * W + threadIdx.x; i < (size_t)H * W; i += 256) g[i] = g[(size_t)last * W + i % W];
 }
 
 // A fused aggregation launch that lost its lock step leaves void path volumes; the launches behind it cannot know and
@@ -3678,33 +3743,41 @@ int rsgm_launch_void_if_lost(vppx_ctx *ctx, float *out, size_t n, const unsigned
     return 0;
 }
 
-int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
-                     float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out)
+int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, int subpixel, float *out)
 {
-    (void)fd;
-    const size_t n = (size_t)g.B * g.H * g.W;
+    const size_t n = (size_t)g.B * g.H * g.W, npf = (size_t)g.H * g.W;
     if (g.W > 8192) { vppx_set_error("frame width %d > 8192 is not supported by the post-processing kernels", g.W); return VPPX_E_UNSUPPORTED; }
-    {
-        const int nby = (g.H - 1) / SPK_TH, nbx = (g.W - 1) / SPK_TW;
-        const size_t npf = (size_t)g.H * g.W;
-        speckle_tile_kernel<<<dim3((g.W + SPK_TW - 1) / SPK_TW, (g.H + SPK_TH - 1) / SPK_TH, g.B), 256, 0, ctx->stream>>>(
-            dl_pad, dr_pad, fdc, fd8, label, lcount, g.H, g.W, g.Hp, g.Wp, g.pad_t, g.pad_l, 0, 10);
-        VPPX_CHECK_LAUNCH();
-        const int nlinks = nby * g.W + nbx * g.H;
-        if (nlinks > 0) {
-            speckle_border_kernel<<<dim3((nlinks + 255) / 256, g.B), 256, 0, ctx->stream>>>(fd8, label, g.H, g.W, 0, 10);
-            VPPX_CHECK_LAUNCH();
-        }
-        const unsigned nblk = (unsigned)((n + 255) / 256);
-        speckle_total_kernel<<<nblk, 256, 0, ctx->stream>>>(label, lcount, npf, g.B);
-        VPPX_CHECK_LAUNCH();
-        speckle_apply_kernel<<<nblk, 256, 0, ctx->stream>>>(fd8, label, lcount, fdc, out, npf, g.B, 0, 200, subpixel);
+    const int ntx = (g.W + SPK_TW - 1) / SPK_TW, nty = (g.H + SPK_TH - 1) / SPK_TH;
+    const size_t ntiles = (size_t)ntx * nty * g.B;
+    u8 *fd8, *row_any;
+    int *label, *size, *roots, *nroots;
+    int rc;
+    if ((rc = ws_get(ctx, WS_FD8, n, &fd8))) return rc;
+    if ((rc = ws_get(ctx, WS_LABEL, n, &label))) return rc;
+    if ((rc = ws_get(ctx, WS_LCOUNT, n, &size))) return rc;
+    if ((rc = ws_get(ctx, WS_SPK_ROOTS, ntiles * (SPK_TW * SPK_TH), &roots))) return rc;
+    if ((rc = ws_get(ctx, WS_SPK_NROOTS, ntiles, &nroots))) return rc;
+    if ((rc = ws_get(ctx, WS_ROW_ANY, (size_t)g.B * g.H, &row_any))) return rc;
+    speckle_tile_kernel<<<dim3(ntx, nty, g.B), 256, 0, ctx->stream>>>(dl_pad, dr_pad, fd8, label, size, roots, nroots, g.H, g.W, g.Hp, g.Wp,
+                                                                      g.pad_t, g.pad_l, 0, 10);
+    VPPX_CHECK_LAUNCH();
+    const int nby = (g.H - 1) / SPK_TH, nbx = (g.W - 1) / SPK_TW;
+    const int nlinks = nby * g.W + nbx * g.H;
+    if (nlinks > 0) {
+        speckle_border_kernel<<<dim3((nlinks + 255) / 256, g.B), 256, 0, ctx->stream>>>(fd8, label, g.H, g.W, 0, 10);
         VPPX_CHECK_LAUNCH();
     }
-    if (g.W <= 2048) interp_bg_rows_kernel<8><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
-    else interp_bg_rows_kernel<32><<<dim3(g.H, g.B), 256, (size_t)g.W * 2 * sizeof(float), ctx->stream>>>(out, g.H, g.W);
+    speckle_total_kernel<<<(unsigned)ntiles, 64, 0, ctx->stream>>>(label, size, roots, nroots, npf, ntx * nty);
     VPPX_CHECK_LAUNCH();
-    interp_bg_cols_kernel<<<dim3((g.W + 63) / 64, g.B), 64 * BGC_RL, 0, ctx->stream>>>(out, g.H, g.W);
+    const size_t lds = (size_t)g.W * 2 * sizeof(float);
+    if (g.W <= 2048)
+        speckle_apply_rows_kernel<8><<<dim3(g.H, g.B), 256, lds, ctx->stream>>>(fd8, label, size, dl_pad, out, row_any, g.H, g.W, g.Hp, g.Wp,
+                                                                               g.pad_t, g.pad_l, 0, 200, subpixel);
+    else
+        speckle_apply_rows_kernel<32><<<dim3(g.H, g.B), 256, lds, ctx->stream>>>(fd8, label, size, dl_pad, out, row_any, g.H, g.W, g.Hp, g.Wp,
+                                                                                g.pad_t, g.pad_l, 0, 200, subpixel);
+    VPPX_CHECK_LAUNCH();
+    interp_bg_edge_rows_kernel<<<g.B, 256, 0, ctx->stream>>>(out, row_any, g.H, g.W);
     VPPX_CHECK_LAUNCH();
     return 0;
 }

@@ -953,15 +953,7 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     { float *t = dl0; dl0 = dl1; dl1 = t; t = dr0; dr0 = dr1; dr1 = t; } // results are in the *1 buffers
 
     const size_t np = (size_t)g.B * g.H * g.W;
-    float *fdc, *fdscr;
-    u8 *fd8;
-    int *label, *lcount;
-    if ((rc = ws_get(ctx, WS_FD, np, &fdscr))) return rc;
-    if ((rc = ws_get(ctx, WS_FDC, np, &fdc))) return rc;
-    if ((rc = ws_get(ctx, WS_FD8, np, &fd8))) return rc;
-    if ((rc = ws_get(ctx, WS_LABEL, np, &label))) return rc;
-    if ((rc = ws_get(ctx, WS_LCOUNT, np, &lcount))) return rc;
-    if ((rc = rsgm_launch_post(ctx, g, dl0, dr0, fdscr, fdc, fd8, label, lcount, p.subpixel, disp_out))) return rc;
+    if ((rc = rsgm_launch_post(ctx, g, dl0, dr0, p.subpixel, disp_out))) return rc;
     // fused layout: should this call's lock-step launch have given up, its output becomes NaN before anything queued
     // behind the call can read it (the host learns of it through vppx_status / vppx_synchronize / the next call)
     if (ctx->last_vert == 3 && ctx->ws[WS_V3ERR].p &&
@@ -1004,16 +996,7 @@ extern "C" int vppx_rsgm_post_dev(vppx_ctx *ctx, int B, int H, int W, const floa
     if ((rc = check_frames(B, H, W, 1))) return rc;
     RsgmGeom g;
     make_geom(B, H, W, 1, 64, g);
-    const size_t np = (size_t)B * H * W;
-    float *fdc, *fdscr;
-    u8 *fd8;
-    int *label, *lcount;
-    if ((rc = ws_get(ctx, WS_FD, np, &fdscr))) return rc;
-    if ((rc = ws_get(ctx, WS_FDC, np, &fdc))) return rc;
-    if ((rc = ws_get(ctx, WS_FD8, np, &fd8))) return rc;
-    if ((rc = ws_get(ctx, WS_LABEL, np, &label))) return rc;
-    if ((rc = ws_get(ctx, WS_LCOUNT, np, &lcount))) return rc;
-    return rsgm_launch_post(ctx, g, disp_l_pad, disp_r_pad, fdscr, fdc, fd8, label, lcount, subpixel, disp_out);
+    return rsgm_launch_post(ctx, g, disp_l_pad, disp_r_pad, subpixel, disp_out);
 }
 
 extern "C" int vppx_rsgm_host(vppx_ctx *ctx, const VppxRsgmParams *p, int B, int H, int W, int C, const uint8_t *left,

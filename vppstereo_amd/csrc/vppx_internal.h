@@ -79,9 +79,10 @@ enum WsSlot {
     WS_DISP_L1,
     WS_DISP_R0,
     WS_DISP_R1,
-    WS_FD,
-    WS_FDC,
     WS_FD8,
+    WS_SPK_ROOTS,    // per tile of the speckle filter: its tile-local roots
+    WS_SPK_NROOTS,
+    WS_ROW_ANY,      // per row of the result: does it hold a valid disparity (column pass of _interpolate_background)
     WS_LABEL,
     WS_LCOUNT,
     WS_P2LUT,
@@ -298,8 +299,7 @@ int rsgm_launch_linear_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const f
 // median3x3 + _linear_interpolate + clip of both views in one launch (fused pipeline)
 int rsgm_launch_median_interp_clip(vppx_ctx *ctx, int B, int Hp, int Wp, const float *src_l, float *dst_l, const float *src_r,
                                    float *dst_r);
-int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, float *fd,
-                     float *fdc, u8 *fd8, int *label, int *lcount, int subpixel, float *out);
+int rsgm_launch_post(vppx_ctx *ctx, const RsgmGeom &g, const float *dl_pad, const float *dr_pad, int subpixel, float *out);
 
 // vpp_kernels.hip
 struct VppGeom {
