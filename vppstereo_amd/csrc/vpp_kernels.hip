@@ -137,15 +137,30 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
     u32 run_cnt = 0, run_drw = 0; // wave-uniform running totals of the row
     unsigned long long *brow = k.bits + ((size_t)f * k.H + y) * vpp_bits_words(k.W);
     if (lane == 0) brow[0] = 0ull, brow[vpp_bits_words(k.W) - 1] = 0ull;
-    for (int p0 = 0; p0 < k.W; p0 += 64) {
+    // (four chunks of 64 columns per round: their hint values and mask bytes are loaded together, unconditionally)
+    for (int pq = 0; pq < k.W; pq += 256) {
+    float gvq[4];
+    u8 ocq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int pc = min(pq + 64 * u + lane, k.W - 1);
+        gvq[u] = k.g[rowoff + (k.direction ? pc : k.W - 1 - pc)];
+    }
+    if (k.occ) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pc = min(pq + 64 * u + lane, k.W - 1);
+            ocq[u] = k.occ[rowoff + (k.direction ? pc : k.W - 1 - pc)];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int p0 = pq + 64 * u;
+        if (p0 >= k.W) break; // uniform
         const int p = p0 + lane;
         const int x = k.direction ? p : k.W - 1 - p;
-        float gv = 0.f;
-        bool is = false;
-        if (p < k.W) {
-            gv = k.g[rowoff + x];
-            is = gv > 0; // NaN and <= 0 are skipped (vpp_core_opt.pyx:81)
-        }
+        const float gv = p < k.W ? gvq[u] : 0.f;
+        const bool is = p < k.W && gv > 0; // NaN and <= 0 are skipped (vpp_core_opt.pyx:81)
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(is);
         if (lane == 0) brow[1 + (p0 >> 6)] = mk; // bit = scan position: the L side finds the hints of a pixel's window here
         if (mk == 0) continue; // uniform
@@ -171,7 +186,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
             r.x = x;
             r.g = gv;
             r.base = my_base;
-            const u32 occ = (k.occ && k.occ[rowoff + x] != 0) ? 1u : 0u;
+            const u32 occ = ocq[u] != 0 ? 1u : 0u;
             r.flags = occ | ((u32)(nk & 0xFF) << 8) | ((cnt & 0xFFFFu) << 16);
             k.rec[rowoff + my_idx] = r;
             k.dense[rowoff + x] = make_uint4(my_idx, my_base, r.flags, __float_as_uint(gv));
@@ -184,6 +199,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
         }
         run_cnt += (u32)__popcll(mk);
         run_drw += (u32)__builtin_amdgcn_readlane((int)vd, 63);
+    }
     }
     if (lane == 0) {
         k.row_count[(size_t)f * k.H + y] = (int)run_cnt;
@@ -835,6 +851,127 @@ __global__ void __launch_bounds__(256) apply_r_px_kernel(VppK k)
         }
     }
 }
+
+// List build and replay of one R row in ONE block (frames narrow enough for the row's lists to sit in LDS).  The hints
+// that can touch row yp are those of rows yp - n .. yp + n: their (hint, target column) items append to the row's lists with
+// LDS atomics -- rlist_kernel's global ones, one L2 operation per item, were what bounded it --, the touched pixels are
+// compacted and replayed from LDS; no count image to clear, to fill and to read back, no lists through memory.
+// Only the second L pass (apply_l_heavy_kernel, apply_l_wide_kernel: r_chain) reads lists of R pixels, and only of pixels an
+// OCCLUDED hint writes (the two pixels it blends into, pyx:114-122) or of column W-1 (the unguarded read of pyx:119): with
+// `lists` those go to memory, and the count of every pixel of the row.
+// IDT: a list entry is (row offset << IB) | index in row: 16 bits when W <= 2048 (IB = 11), else 32 (IB = 16).
+// mode bit 0: replay, bit 1: write the lists out.
+template <typename IDT, int IB, int NT>
+__global__ void __launch_bounds__(NT) r_rows_kernel(VppK k, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+    __shared__ int s_off[33];
+    __shared__ int s_total;
+    const int W = k.W, H = k.H, n = k.n;
+    const int yp = blockIdx.x, f = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63;
+    u32 *s_cnt = s_dyn;                                  // [W] low half: hints on the pixel, high half: occluded ones among them
+    IDT *s_list = (IDT *)(s_dyn + W);                    // [W][RLCAP]
+    unsigned short *s_touch = (unsigned short *)(s_list + (size_t)W * RLCAP); // [W] touched columns
+    const int span = 2 * n + 1, tw = 2 * n + 2;          // source rows, columns of a hint's target range
+    for (int q = t; q < W; q += NT) s_cnt[q] = 0;
+    if (t == 0) s_total = 0;
+    if (t < 64) { // items per source row and their prefix (span <= 31)
+        const int yy = yp - n + t;
+        int c = (t < span && yy >= 0 && yy <= H - 1) ? k.row_count[(size_t)f * H + yy] * tw : 0;
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (t <= 32) s_off[t] = inc - c; // exclusive; s_off[span] = total
+    }
+    __syncthreads();
+    const int total_items = s_off[span];
+    for (int t0 = t; t0 < total_items; t0 += NT * 4) {
+        int rr[4], ii[4], tqv[4];
+        u32 rgs[4], fl[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int it = min(t0 + NT * u, total_items - 1);
+            int r = 0;
+            while (r + 1 < span && s_off[r + 1] <= it) r++;
+            const int loc = it - s_off[r];
+            rr[u] = r;
+            ii[u] = loc / tw;
+            tqv[u] = loc % tw;
+            const size_t ro = ((size_t)f * H + (yp - n + r)) * W + ii[u];
+            rgs[u] = k.rng[ro];
+            fl[u] = k.rec[ro].flags;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t0 + NT * u >= total_items) continue;
+            const int lo = (int)(short)(rgs[u] & 0xFFFFu), hi = (int)(short)(rgs[u] >> 16);
+            const u32 add = 1u + ((fl[u] & 1u) << 16);
+            const IDT id = (IDT)(((u32)rr[u] << IB) | (u32)ii[u]);
+            const int q = lo + tqv[u];
+            if (q >= 0 && q <= hi && q <= W - 1) {
+                const u32 slot = atomicAdd(&s_cnt[q], add) & 0xFFFFu;
+                if (slot < RLCAP) s_list[(size_t)q * RLCAP + slot] = id;
+            }
+            // Python-style wraparound target, column W-1 (SURVEY C-1/C-2): only the un-interpolated write
+            // r[.., xd+xw] with xd = xd0-1 and xd0+xw == 0 can index -1 (pyx:113,121), i.e. lo < 0 <= hi
+            if (tqv[u] == 0 && !k.interp && lo < 0 && hi >= 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi)) {
+                const u32 slot = atomicAdd(&s_cnt[W - 1], add) & 0xFFFFu;
+                if (slot < RLCAP) s_list[(size_t)(W - 1) * RLCAP + slot] = id;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t prow = ((size_t)f * H + yp) * W;
+    for (int qb = t & ~63; qb < W; qb += NT) { // (whole waves)
+        const int q = qb + lane;
+        const u32 c = q < W ? s_cnt[q] : 0u;
+        if ((mode & 2) && q < W) k.rcnt[prow + q] = (int)(c & 0xFFFFu);
+        const bool hit = (c & 0xFFFFu) != 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+        if (bal) {
+            const int leader = __builtin_ctzll(bal);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_total, (int)__popcll(bal));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (hit) s_touch[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (unsigned short)q;
+        }
+    }
+    __syncthreads();
+    const int total = s_total;
+    for (int e = t; e < total; e += NT) {
+        const int q = s_touch[e];
+        const u32 c = s_cnt[q];
+        const int cnt = (int)(c & 0xFFFFu);
+        const size_t pidx = prow + q;
+        u32 ids[RLCAP];
+#pragma unroll
+        for (int i = 0; i < RLCAP; i++) {
+            const u32 pk = (u32)s_list[(size_t)q * RLCAP + i];
+            ids[i] = ((u32)(yp - n + (int)(pk >> IB)) << 16) | (pk & ((1u << IB) - 1u));
+        }
+        if ((mode & 2) && ((c >> 16) != 0 || q == W - 1)) {
+            uint4 *dst = (uint4 *)k.rlist + pidx * 2;
+            dst[0] = make_uint4(ids[0], ids[1], ids[2], ids[3]);
+            dst[1] = make_uint4(ids[4], ids[5], ids[6], ids[7]);
+        }
+        if (!(mode & 1)) continue;
+        if (cnt <= RLCAP) {
+            r_replay_list(k, f, yp, q, pidx, cnt, ids);
+        } else { // overflowed list (typically column W-1, the wraparound target of every hint near the left border)
+            u8 *px = k.r + pidx * k.C;
+            u8 R[4] = {0, 0, 0, 0};
+            for (int j = 0; j < k.C; j++) R[j] = px[j];
+            r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
+            for (int j = 0; j < k.C; j++) px[j] = R[j];
+        }
+    }
+}
+#define RR_NT 256 // (192 .. 256 threads per row measure the same, 320 and more lose a third)
+static size_t r_rows_lds(int W, bool wide_ids) { return (size_t)W * (4 + RLCAP * (wide_ids ? 4 : 2) + 2) + 16; }
 
 // ---------------------------------------------------------------------------------------
 // 4. L pixels (they replay R chains from the ORIGINAL right image: before apply_r_px_kernel unless the caller kept a copy)
@@ -1854,9 +1991,6 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     // in one pass -- the first pass is a tenth of the code and runs with twice the waves per SIMD)
     const bool two_pass = occ != nullptr && !k.discard && k.n <= 3;
     if (!two_pass) k.lwork = nullptr; // (rowscan_kernel has zeroed the work-list counter)
-    // With two passes the first one never looks at R (it defers every pixel that would): it starts right away on the side
-    // stream, next to the list build; only the second pass waits for the lists.
-    const bool light_early = two_pass && split_late;
     auto launch_l_hint = [&](hipStream_t st) {
         if (k.n > 3) return; // (apply_l_wide_kernel below)
         // rows per block: four, so that the touched pixels fill whole rounds of the block's replay; one when a call has too few
@@ -1873,44 +2007,97 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         }
 #undef LB
     };
-    hipStream_t ls = ctx->stream;
-    if (split_early || light_early) {
-        VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-        VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        ls = ctx->stream2;
-    }
-    if (light_early) {
-        launch_l_hint(ls);
-        VPPX_CHECK_LAUNCH();
-    }
-    VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
-    rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
-    VPPX_CHECK_LAUNCH();
-    if (split_late) {
-        VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-        VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        ls = ctx->stream2;
-    }
-    if (!light_early) {
-        launch_l_hint(ls);
-        VPPX_CHECK_LAUNCH();
-    }
-    if (two_pass) {
+    auto launch_l_heavy = [&](hipStream_t st) {
         const dim3 hg((unsigned)(g.B * 512 < 32768 ? g.B * 512 : 32768)); // (about one deferred pixel per pair of lanes at 3 % hints: the replays are latency chains)
         switch (k.n) {
-        case 0: apply_l_heavy_kernel<1><<<hg, 64, 0, ls>>>(k); break;
-        case 1: apply_l_heavy_kernel<3><<<hg, 64, 0, ls>>>(k); break;
-        case 2: apply_l_heavy_kernel<5><<<hg, 64, 0, ls>>>(k); break;
-        default: apply_l_heavy_kernel<7><<<hg, 64, 0, ls>>>(k); break;
+        case 0: apply_l_heavy_kernel<1><<<hg, 64, 0, st>>>(k); break;
+        case 1: apply_l_heavy_kernel<3><<<hg, 64, 0, st>>>(k); break;
+        case 2: apply_l_heavy_kernel<5><<<hg, 64, 0, st>>>(k); break;
+        default: apply_l_heavy_kernel<7><<<hg, 64, 0, st>>>(k); break;
         }
-        VPPX_CHECK_LAUNCH();
+    };
+    // R rows in LDS (r_rows_kernel) where a row's lists fit, else lists through memory (rlist_kernel + apply_r_px_kernel)
+    const bool wide_ids = g.W > 2048;
+    const size_t rows_lds = r_rows_lds(g.W, wide_ids);
+    const bool r_rows = rows_lds <= 128 * 1024;
+    if (r_rows && rows_lds > 48 * 1024) {
+        static bool attr_set[VPPX_MAX_DEVICES][2] = {};
+        if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)][wide_ids]) {
+            if (wide_ids) VPPX_HIP(hipFuncSetAttribute((const void *)r_rows_kernel<u32, 16, RR_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            else VPPX_HIP(hipFuncSetAttribute((const void *)r_rows_kernel<unsigned short, 11, RR_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)][wide_ids] = true;
+        }
     }
-    if (k.n > 3) apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k);
-    VPPX_CHECK_LAUNCH();
-    {
+    const bool need_lists = occ != nullptr && !k.discard; // some L kernel replays R sub-chains (r_chain)
+    if (!need_lists) k.rcnt = nullptr;
+    auto launch_r_rows = [&](int mode) {
+        if (wide_ids) r_rows_kernel<u32, 16, RR_NT><<<dim3(g.H, g.B), RR_NT, rows_lds, ctx->stream>>>(k, mode);
+        else r_rows_kernel<unsigned short, 11, RR_NT><<<dim3(g.H, g.B), RR_NT, rows_lds, ctx->stream>>>(k, mode);
+    };
+    auto launch_r_lists = [&]() -> int { // lists through memory
+        VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
+        rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
+        VPPX_CHECK_LAUNCH();
+        return 0;
+    };
+    auto launch_r_px = [&]() {
         const size_t npf = (size_t)g.H * g.W;
         if (npf * g.B >= (size_t)4096 * 1024) apply_r_px_kernel<16><<<dim3((unsigned)((npf + 4095) / 4096), g.B), 256, 0, ctx->stream>>>(k);
         else apply_r_px_kernel<4><<<dim3((unsigned)((npf + 1023) / 1024), g.B), 256, 0, ctx->stream>>>(k);
+    };
+    hipStream_t ls = ctx->stream;
+    if (split) { // the L side on the side stream from here on
+        VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        ls = ctx->stream2;
+    }
+    if (!need_lists) {
+        // no L kernel looks at R: the two sides are independent
+        launch_l_hint(ls);
+        VPPX_CHECK_LAUNCH();
+        if (k.n > 3) apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k);
+        VPPX_CHECK_LAUNCH();
+        if (r_rows) {
+            launch_r_rows(1);
+        } else {
+            k.rcnt = nullptr;
+            if ((rc = ws_get(ctx, WS_RCNT, npx, &k.rcnt))) return rc;
+            if ((rc = launch_r_lists())) return rc;
+            launch_r_px();
+        }
+        VPPX_CHECK_LAUNCH();
+    } else if (split_late) {
+        // the caller kept the original right image: the R side runs right away (building the lists as it goes), the first
+        // L pass next to it; only the passes that replay R sub-chains wait for the lists
+        if (two_pass) {
+            launch_l_hint(ls);
+            VPPX_CHECK_LAUNCH();
+        }
+        if (r_rows) {
+            launch_r_rows(3);
+        } else {
+            if ((rc = launch_r_lists())) return rc;
+        }
+        VPPX_CHECK_LAUNCH();
+        VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        VPPX_HIP(hipStreamWaitEvent(ls, ctx->ev_fork, 0));
+        if (!r_rows) launch_r_px();
+        VPPX_CHECK_LAUNCH();
+        if (two_pass) launch_l_heavy(ls);
+        else apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k); // (n > 3)
+        VPPX_CHECK_LAUNCH();
+    } else {
+        // R is patterned in place: every L pass that reads it comes first
+        if (r_rows) launch_r_rows(2);
+        else if ((rc = launch_r_lists())) return rc;
+        VPPX_CHECK_LAUNCH();
+        launch_l_hint(ls);
+        VPPX_CHECK_LAUNCH();
+        if (two_pass) launch_l_heavy(ls);
+        if (k.n > 3) apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k);
+        VPPX_CHECK_LAUNCH();
+        if (r_rows) launch_r_rows(1);
+        else launch_r_px();
         VPPX_CHECK_LAUNCH();
     }
     if (split) {
@@ -2019,28 +2206,63 @@ __global__ void __launch_bounds__(256) occ_warp_kernel(const float *__restrict__
 // an image of winners nor atomics:  out[y, x] = conf of omap[y, x - round(v)] if the hint at x owns that pixel
 // (omap == v) and the filter keeps it, 1 everywhere else (the initial value of conf_unwarp, :101).
 // The confidence in gather form: pixel n = (y, xd) of omap is rejected if some valid centre c with n in c's window is
-// nearer (larger) by more than the weighted distance.  Owners are sparse (the hints, a few per cent): the wave takes
-// them two at a time and tests all window positions of both at once, one per lane and NJ per owner; the loads are
-// unconditional at clamped coordinates (hipcc does not speculate loads: a conditional one costs a branch and a full
-// wait each) so that all 2 NJ are in flight together.
+// nearer (larger) by more than the weighted distance.  Owners are sparse (the hints, a few per cent).  A block owns 1024
+// pixels of a row: it loads their hints and the pixels of omap they land on (four per thread, in flight together),
+// collects the owners in LDS, and its waves then take them four at a time and test all window positions of the four at
+// once, one per lane and NJ per owner; the loads are unconditional at clamped coordinates (hipcc does not speculate
+// loads: a conditional one costs a branch and a full wait each) so that all 4 NJ are in flight together.
 template <int NJ>
 __global__ void __launch_bounds__(256) occ_test_kernel(const float *__restrict__ hints, const float *__restrict__ omap,
                                                        u8 *__restrict__ out, int *__restrict__ tmp, int H, int W, int rx,
                                                        int ry, double l, double g, double th, double th_filter)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_xd[1024];
+    __shared__ float s_v[1024];
+    __shared__ unsigned short s_px[1024];
+    __shared__ u8 s_cf[1024];
+    __shared__ int s_total;
+    const int x0 = blockIdx.x * 1024;
     const int y = blockIdx.y, f = blockIdx.z;
-    const int lane = threadIdx.x & 63;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const float *om = omap + (size_t)f * H * W;
     const size_t row = ((size_t)f * H + y) * W;
-    const float v = x < W ? hints[row + x] : 0.0f;
-    const int xd = x - (int)rintf(v);
-    const bool lands = v > 0 && 0 <= xd && xd <= W - 1;
-    const float at = om[(size_t)y * W + min(max(xd, 0), W - 1)];
-    const bool owner = lands && at == v;
-    int cf = 0;
+    if (t == 0) s_total = 0;
+    float v[4], at[4];
+    int xd[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int x = x0 + 256 * u + t;
+        v[u] = hints[row + min(x, W - 1)];
+        if (x >= W) v[u] = 0.0f;
+        s_cf[256 * u + t] = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        xd[u] = x0 + 256 * u + t - (int)rintf(v[u]);
+        at[u] = om[(size_t)y * W + min(max(xd[u], 0), W - 1)];
+    }
+    __syncthreads();
+    bool owner[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        owner[u] = v[u] > 0 && 0 <= xd[u] && xd[u] <= W - 1 && at[u] == v[u];
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(owner[u]);
+        if (bal) {
+            const int leader = __builtin_ctzll(bal);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_total, (int)__popcll(bal));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (owner[u]) {
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                s_xd[slot] = xd[u];
+                s_v[slot] = v[u];
+                s_px[slot] = (unsigned short)(256 * u + t);
+            }
+        }
+    }
+    __syncthreads();
+    const int total = s_total;
     const int nyw = 2 * ry + 2, nwin = (2 * rx + 1) * nyw; // centre = (y - yw, xd - xw), xw in [-rx,rx], yw in [-ry-1,ry] (:149)
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(owner);
     if (NJ > 0) {
         // a lane's window positions (lane, lane + 64, ...) and their distance weights do not depend on the pixel under
         // test: worked out once (the integer divisions and four of the five float64 operations of every test)
@@ -2057,39 +2279,37 @@ __global__ void __launch_bounds__(256) occ_test_kernel(const float *__restrict__
             inj[j] = kpos < nwin && yc >= 0 && yc <= H - 1;
             ycj[j] = min(max(yc, 0), H - 1);
         }
-        while (todo) {
-            const int s0 = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const bool two = todo != 0;
-            const int s1 = two ? __builtin_ctzll(todo) : s0;
-            todo &= todo - 1; // 0 stays 0
-            const int xs0 = __builtin_amdgcn_readlane(xd, s0), xs1 = __builtin_amdgcn_readlane(xd, s1);
-            const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s0));
-            const float d1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s1));
-            float c0[NJ > 0 ? NJ : 1], c1[NJ > 0 ? NJ : 1];
+        for (int e0 = 4 * wv; e0 < total; e0 += 16) {
+            int xs[4];
+            float ds[4], c[4][NJ > 0 ? NJ : 1];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = e0 + i < total ? e0 + i : e0;
+                xs[i] = s_xd[e];
+                ds[i] = s_v[e];
+            }
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
                 const float *r = om + (size_t)ycj[j] * W;
-                c0[j] = r[min(max(xs0 - xwj[j], 0), W - 1)];
-                c1[j] = r[min(max(xs1 - xwj[j], 0), W - 1)];
-            }
-            bool h0 = false, h1 = false;
 #pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                const int xc0 = xs0 - xwj[j], xc1 = xs1 - xwj[j];
-                const bool in0 = inj[j] && xc0 >= 0 && xc0 <= W - 1, in1 = inj[j] && xc1 >= 0 && xc1 <= W - 1;
-                if (in0 && c0[j] > 0 && d0 < c0[j]) h0 = h0 || (__dsub_rn((double)__fsub_rn(c0[j], d0), wgj[j]) > th);
-                if (in1 && c1[j] > 0 && d1 < c1[j]) h1 = h1 || (__dsub_rn((double)__fsub_rn(c1[j], d1), wgj[j]) > th);
+                for (int i = 0; i < 4; i++) c[i][j] = r[min(max(xs[i] - xwj[j], 0), W - 1)];
             }
-            const bool a0 = __builtin_amdgcn_ballot_w64(h0) != 0, a1 = __builtin_amdgcn_ballot_w64(h1) != 0;
-            if ((a0 && lane == s0) || (a1 && lane == s1)) cf = 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bool h = false;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const int xc = xs[i] - xwj[j];
+                    if (inj[j] && xc >= 0 && xc <= W - 1 && c[i][j] > 0 && ds[i] < c[i][j])
+                        h = h || (__dsub_rn((double)__fsub_rn(c[i][j], ds[i]), wgj[j]) > th);
+                }
+                if (__builtin_amdgcn_ballot_w64(h) != 0 && lane == 0 && e0 + i < total) s_cf[s_px[e0 + i]] = 1;
+            }
         }
     } else {
-        while (todo) { // windows of more than 256 positions
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int xs = __builtin_amdgcn_readlane(xd, src);
-            const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+        for (int e = wv; e < total; e += 4) { // windows of more than 256 positions: a wave per owner
+            const int xs = s_xd[e];
+            const float ds = s_v[e];
             bool hit = false;
             for (int kpos = lane; kpos < nwin; kpos += 64) {
                 const int xw = kpos / nyw - rx, yw = kpos % nyw - ry - 1;
@@ -2097,19 +2317,25 @@ __global__ void __launch_bounds__(256) occ_test_kernel(const float *__restrict__
                 if (yc < 0 || yc > H - 1 || xc < 0 || xc > W - 1) continue;
                 const float dc = om[(size_t)yc * W + xc];
                 if (dc > 0 && ds < dc) {
-                    const double t = __dsub_rn((double)__fsub_rn(dc, ds),
-                                               __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xw)),
-                                                                      __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw)))));
-                    hit = hit || (t > th);
+                    const double tt = __dsub_rn((double)__fsub_rn(dc, ds),
+                                                __dmul_rn(l, __dadd_rn(__dmul_rn(g, (double)abs(xw)),
+                                                                       __dmul_rn(__dsub_rn(1.0, g), (double)abs(yw)))));
+                    hit = hit || (tt > th);
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(hit) != 0 && lane == src) cf = 1;
+            if (__builtin_amdgcn_ballot_w64(hit) != 0 && lane == 0) s_cf[s_px[e]] = 1;
         }
     }
-    if (x >= W) return;
-    const bool kept = owner && !((double)cf > th_filter); // filter (:168-194) drops a pixel of omap whose confidence is above the threshold
-    out[row + x] = kept ? (u8)cf : (u8)1;
-    if (tmp) tmp[row + x] = kept ? ((xd << 1) | cf) : -1; // where the value of element [0] sits in omap (occ_dmap_kernel)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int x = x0 + 256 * u + t;
+        if (x >= W) continue;
+        const int cf = s_cf[256 * u + t];
+        const bool kept = owner[u] && !((double)cf > th_filter); // filter (:168-194) drops a pixel of omap whose confidence is above the threshold
+        out[row + x] = kept ? (u8)cf : (u8)1;
+        if (tmp) tmp[row + x] = kept ? ((xd[u] << 1) | cf) : -1; // where the value of element [0] sits in omap (occ_dmap_kernel)
+    }
 }
 
 // Element [0] of occlusion_heuristic (filter.py:283-292): left_unwarp of the filtered omap (:51-79, last writer in raster
@@ -2148,7 +2374,7 @@ int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, i
                double th_conf, double th_filter, float *omap, u8 *conf_out, float *dmap_out)
 {
     const size_t n = (size_t)B * H * W;
-    dim3 grid((W + 255) / 256, H, B);
+    dim3 grid((W + 255) / 256, H, B), grid_t((W + 1023) / 1024, H, B);
     int *tmp = nullptr;
     if (dmap_out) {
         int rc = ws_get(ctx, WS_OCC_TMP, n, &tmp);
@@ -2159,7 +2385,7 @@ int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, i
     VPPX_CHECK_LAUNCH();
     rx /= 2, ry /= 2; // filter.py:142-143
     const long long nwin = (2LL * rx + 1) * (2LL * ry + 2);
-#define OCC_TEST(NJ) occ_test_kernel<NJ><<<grid, 256, 0, ctx->stream>>>(hints, omap, conf_out, tmp, H, W, rx, ry, l, g, th_conf, th_filter)
+#define OCC_TEST(NJ) occ_test_kernel<NJ><<<grid_t, 256, 0, ctx->stream>>>(hints, omap, conf_out, tmp, H, W, rx, ry, l, g, th_conf, th_filter)
     if (nwin <= 64) OCC_TEST(1);
     else if (nwin <= 128) OCC_TEST(2);
     else if (nwin <= 192) OCC_TEST(3);
