@@ -140,7 +140,10 @@ def test_rnd_full_size_anchor_hashes(gpu, anchors):
 
 
 @pytest.mark.parametrize("H,W,C,p,dmax", [(37, 53, 3, 0.07, 20.0), (64, 300, 1, 0.03, 190.0), (5, 7, 3, 0.5, 4.0),
-                                          (120, 260, 3, 0.25, 60.0)])
+                                          (120, 260, 3, 0.25, 60.0),
+                                          # rows of 2048 (the last width whose R lists use 16-bit entries in LDS), wider (32-bit
+                                          # entries), and too wide for LDS (lists through memory)
+                                          (9, 2048, 3, 0.04, 100.0), (7, 2300, 3, 0.03, 60.0), (6, 3700, 1, 0.05, 40.0)])
 def test_rnd_vs_oracle_random_inputs(gpu, H, W, C, p, dmax):
     rng = np.random.default_rng(H * 1000 + W)
     for trial in range(6):
@@ -278,8 +281,8 @@ def test_batched_vpp_is_sharding_independent():
                                 dict(wsize=5, interpolate=1, direction=0), dict(wsize=7, interpolate=0, uniform_color=1),
                                 dict(wsize=1, interpolate=1)])
 def test_mixed_density_batch_uses_both_thread_mappings(kw):
-    """One batch whose frames fall on both sides of the per-frame sparse/dense switch of the L and R
-    kernels (hints x patch area vs pixels), with occluded hints, hints hugging the left border
+    """One batch whose frames run from no hints at all to a hint on every pixel (R lists that overflow,
+    windows full of hints), with occluded hints, hints hugging the left border
     (targets < 0, the -1 wraparound of the un-interpolated write) and large disparities."""
     from vppstereo_amd import _lib
     lib, ctx = _lib.load(), _lib.default_context()
