@@ -20,7 +20,7 @@
 //                       jump-ahead (x_n = x_{n-3} + x_{n-31} mod 2^32 is linear)
 //   4. apply_l_bits_kernel  : L pixels whose window holds a hint (found in the bitmaps, compacted through LDS);
 //      apply_l_heavy_kernel : the ones with an occluded hint (they replay R sub-chains), a pair of lanes each
-//   5. rlist_kernel + apply_r_px_kernel : per-R-pixel hint lists, then the touched R pixels (compacted through LDS)
+//   5. r_rows_kernel : per-R-pixel hint lists of a row in LDS, then the touched R pixels (compacted through LDS)
 // Mixed float32/float64 blend arithmetic follows the C that Cython generates;
 // the library is compiled with -ffp-contract=off and uses explicit _rn intrinsics.
 #include "vppx_internal.h"
@@ -128,7 +128,9 @@ __device__ __forceinline__ int hint_idx(const VppK &k, int f, int y, int x, floa
 // ---------------------------------------------------------------------------------------
 // (one wave per row, four rows per block: the hints of 64 columns are numbered by a ballot and a lane-mask popcount, their
 // draws by one wave scan -- no block barriers; round 3: stage 0.16 -> 0.14 ms per 32 frames, two 50 MB copies included)
-__global__ void __launch_bounds__(256) compact_kernel(VppK k)
+#define CK_NG 16
+template <bool DIST> // use_distance_patch: the radius of a patch is a float64 pow() of its hint (registers the common case does not pay for)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) compact_kernel(VppK k)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int y = blockIdx.x * 4 + wv, f = blockIdx.y;
@@ -137,29 +139,41 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
     u32 run_cnt = 0, run_drw = 0; // wave-uniform running totals of the row
     unsigned long long *brow = k.bits + ((size_t)f * k.H + y) * vpp_bits_words(k.W);
     if (lane == 0) brow[0] = 0ull, brow[vpp_bits_words(k.W) - 1] = 0ull;
-    // (four chunks of 64 columns per round: their hint values and mask bytes are loaded together, unconditionally)
-    for (int pq = 0; pq < k.W; pq += 256) {
-    float gvq[4];
-    u8 ocq[4] = {0, 0, 0, 0};
+    // (CK_NG chunks of 64 columns per round -- a whole row of up to 1024 columns: their hint values and mask bytes are
+    // loaded together, unconditionally.  Next to the sum / WTA kernel of the previous part, whose one block per CU leaves
+    // room for a wave or two per SIMD, a round trip through memory takes several microseconds: they are what this
+    // kernel's time is made of there.)
+    for (int pq = 0; pq < k.W; pq += 64 * CK_NG) {
+    float gvq[CK_NG];
+    u32 ocq[CK_NG / 4]; // the mask bytes, four to a register
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < CK_NG / 4; u++) ocq[u] = 0;
+#pragma unroll
+    for (int u = 0; u < CK_NG; u++) {
         const int pc = min(pq + 64 * u + lane, k.W - 1);
         gvq[u] = k.g[rowoff + (k.direction ? pc : k.W - 1 - pc)];
     }
     if (k.occ) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < CK_NG; u++) {
             const int pc = min(pq + 64 * u + lane, k.W - 1);
-            ocq[u] = k.occ[rowoff + (k.direction ? pc : k.W - 1 - pc)];
+            ocq[u / 4] |= (u32)k.occ[rowoff + (k.direction ? pc : k.W - 1 - pc)] << (8 * (u % 4));
         }
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
+#pragma unroll 1 // (one copy of the body -- patch_radius alone is 170 float64 instructions --: the chunk's values are picked out of the registers)
+    for (int u = 0; u < CK_NG; u++) {
         const int p0 = pq + 64 * u;
         if (p0 >= k.W) break; // uniform
         const int p = p0 + lane;
         const int x = k.direction ? p : k.W - 1 - p;
-        const float gv = p < k.W ? gvq[u] : 0.f;
+        float gsel = gvq[0];
+        u32 osel = ocq[0];
+#pragma unroll
+        for (int j = 1; j < CK_NG; j++) gsel = u == j ? gvq[j] : gsel;
+#pragma unroll
+        for (int j = 1; j < CK_NG / 4; j++) osel = (u >> 2) == j ? ocq[j] : osel;
+        osel = (osel >> (8 * (u & 3))) & 0xFFu;
+        const float gv = p < k.W ? gsel : 0.f;
         const bool is = p < k.W && gv > 0; // NaN and <= 0 are skipped (vpp_core_opt.pyx:81)
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(is);
         if (lane == 0) brow[1 + (p0 >> 6)] = mk; // bit = scan position: the L side finds the hints of a pixel's window here
@@ -167,7 +181,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
         int nk = 0;
         u32 cnt = 0, drw = 0;
         if (is) {
-            nk = patch_radius(k, gv);
+            nk = DIST ? patch_radius(k, gv) : k.n;
             cnt = (u32)hint_cnt(k, f, y, x, gv, nk);
             drw = k.uniform ? (u32)k.C : (u32)k.C * cnt;
         }
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(256) compact_kernel(VppK k)
             r.x = x;
             r.g = gv;
             r.base = my_base;
-            const u32 occ = ocq[u] != 0 ? 1u : 0u;
+            const u32 occ = osel != 0 ? 1u : 0u;
             r.flags = occ | ((u32)(nk & 0xFF) << 8) | ((cnt & 0xFFFFu) << 16);
             k.rec[rowoff + my_idx] = r;
             k.dense[rowoff + x] = make_uint4(my_idx, my_base, r.flags, __float_as_uint(gv));
@@ -635,7 +649,7 @@ __device__ __forceinline__ bool rng_hit(u32 rg, int q, int W)
 __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim_y, int lim_i, int lim_xw)
 {
     const int W = k.W, H = k.H;
-    // the pixel's hint list (rlist_kernel has run before every caller) names exactly the hints that can touch it:
+    // the pixel's hint list (r_rows_kernel has written it out before every caller) names exactly the hints that can touch it:
     // replay those up to the limit key instead of scanning the hint rows (a few entries instead of ~3 rows of hints)
     if (k.rcnt != nullptr && lim_y < H) {
         const size_t pidx = ((size_t)f * H + yp) * W + q;
@@ -694,63 +708,7 @@ __device__ void r_chain(const VppK &k, int f, int yp, int q, u8 (&R)[4], int lim
 }
 
 // ---------------------------------------------------------------------------------------
-// 4b. per-R-pixel hint lists: thread (hint, yw, target column) appends the hint to the R pixel of
-// row y+yw at that column of the hint's target range.  Only ~1/3 of the R pixels are touched at all
-// and almost all by one or two hints, so the R kernel replays exactly those instead of scanning
-// whole hint rows.  Lists are unordered (atomics); the consumer sorts by scan rank.
-// ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) rlist_kernel(VppK k)
-{
-    const int y = blockIdx.x, f = blockIdx.y;
-    const int W = k.W, H = k.H;
-    const size_t rowoff = ((size_t)f * H + y) * W;
-    const int cnt = k.row_count[(size_t)f * H + y];
-    const int span = 2 * k.n + 1, tw = 2 * k.n + 2; // rows of the patch, columns of the target range
-    const int total = cnt * span * tw;
-    // (four items per thread and round: their range loads, then their atomics, then their stores are in flight together --
-    // a round is three dependent trips through memory whatever the number of items)
-    for (int t0 = threadIdx.x; t0 < total; t0 += 256 * 4) {
-        u32 rgs[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) rgs[u] = k.rng[rowoff + min(t0 + 256 * u, total - 1) / (span * tw)];
-        size_t at[4], at2[4];
-        bool on[4], on2[4];
-        u32 idv[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = t0 + 256 * u;
-            const int i = t / (span * tw), rem = t % (span * tw);
-            const int yw = rem / tw - k.n, tq = rem % tw;
-            const int yp = y + yw;
-            const bool ok = t < total && yp >= 0 && yp <= H - 1;
-            const u32 rg = rgs[u];
-            const int lo = (int)(short)(rg & 0xFFFFu), hi = (int)(short)(rg >> 16);
-            const size_t prow = ((size_t)f * H + min(max(yp, 0), H - 1)) * W;
-            idv[u] = ((u32)y << 16) | (u32)i;
-            const int q = lo + tq;
-            on[u] = ok && q >= 0 && q <= hi && q <= W - 1;
-            at[u] = prow + (size_t)min(max(q, 0), W - 1);
-            // Python-style wraparound target, column W-1 (SURVEY C-1/C-2): only the un-interpolated write
-            // r[.., xd+xw] with xd = xd0-1 and xd0+xw == 0 can index -1 (pyx:113,121), i.e. lo < 0 <= hi
-            on2[u] = ok && tq == 0 && !k.interp && lo < 0 && hi >= 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi);
-            at2[u] = prow + W - 1;
-        }
-        int slot[4], slot2[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            slot[u] = on[u] ? atomicAdd(&k.rcnt[at[u]], 1) : RLCAP;
-            slot2[u] = on2[u] ? atomicAdd(&k.rcnt[at2[u]], 1) : RLCAP;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (slot[u] < RLCAP) k.rlist[at[u] * RLCAP + slot[u]] = idv[u];
-            if (slot2[u] < RLCAP) k.rlist[at2[u] * RLCAP + slot2[u]] = idv[u];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// 5. R pixels: one thread per pixel replays the hints of its list in scan order; untouched
+// 5. R pixels: one thread per touched pixel replays the hints of its list in scan order; untouched
 // pixels are not even read.  A list that overflowed (> RLCAP hints on one pixel: very dense
 // hints) falls back to scanning the hint rows.
 // ---------------------------------------------------------------------------------------
@@ -780,7 +738,10 @@ __device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int 
     const int hi0 = (int)(ids[0] & 0xFFFFu), hi1 = n > 1 ? (int)(ids[1] & 0xFFFFu) : hi0;
     const HintRec rec0 = k.rec[((size_t)f * H + yy0) * k.W + hi0], rec1 = k.rec[((size_t)f * H + yy1) * k.W + hi1];
     const u32 rb0 = k.row_base[(size_t)f * H + yy0], rb1 = k.row_base[(size_t)f * H + yy1];
-    r_apply_rec2(k, f, yp, q, R, yy0, rec0, rnd_f + rb0, 0x7FFFFFFF, n > 1, yy1, rec1, rnd_f + rb1, 0x7FFFFFFF);
+    // (callers hand a wave pixels with lists of the same length where they can: a wave of one-entry lists skips the second
+    // record's half of the work)
+    if (__builtin_amdgcn_ballot_w64(n > 1) == 0) r_apply_rec(k, f, yp, yy0, rec0, q, R, rnd_f + rb0, 0x7FFFFFFF);
+    else r_apply_rec2(k, f, yp, q, R, yy0, rec0, rnd_f + rb0, 0x7FFFFFFF, n > 1, yy1, rec1, rnd_f + rb1, 0x7FFFFFFF);
 #pragma unroll 1
     for (int i = 2; i < n; i++) {
         const u32 id = i == 2 ? ids[2] : i == 3 ? ids[3] : i == 4 ? ids[4] : i == 5 ? ids[5] : i == 6 ? ids[6] : ids[7];
@@ -789,93 +750,35 @@ __device__ __forceinline__ void r_replay_list(const VppK &k, int f, int yp, int 
     }
     for (int j = 0; j < k.C; j++) px[j] = R[j];
 }
-// the whole list record of a pixel: two 16-byte loads (RLCAP = 8 entries of 4 bytes, 32-byte aligned)
-__device__ __forceinline__ void r_load_list(const VppK &k, size_t pidx, u32 (&ids)[RLCAP])
-{
-    static_assert(RLCAP == 8, "list record = 2 x uint4");
-    const uint4 a = ((const uint4 *)k.rlist)[pidx * 2], b = ((const uint4 *)k.rlist)[pidx * 2 + 1];
-    ids[0] = a.x; ids[1] = a.y; ids[2] = a.z; ids[3] = a.w;
-    ids[4] = b.x; ids[5] = b.y; ids[6] = b.z; ids[7] = b.w;
-}
-
-// The same in pixel-driven form with compaction, for every frame: a block reads the list lengths of 256 * PXT
-// consecutive pixels (coalesced), appends the touched ones -- about one in three -- to a list in LDS, and replays them
-// with full waves.  (The hint-driven kernel above spends most of its time finding out, item by item, which thread owns a
-// pixel: four scattered loads per (hint, patch row, column) item, five items per touched pixel.)
-template <int PXT>
-__global__ void __launch_bounds__(256) apply_r_px_kernel(VppK k)
-{
-    __shared__ unsigned short s_list[256 * PXT];
-    __shared__ int s_total;
-    const int W = k.W, H = k.H, f = blockIdx.y;
-    const size_t npf = (size_t)H * W, i0 = (size_t)blockIdx.x * (256 * PXT);
-    const int t = threadIdx.x, lane = t & 63;
-    if (t == 0) s_total = 0;
-    __syncthreads();
-    int nn[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; j++) {
-        const size_t i = i0 + j * 256 + t;
-        nn[j] = k.rcnt[f * npf + (i < npf ? i : npf - 1)];
-        nn[j] = i < npf ? nn[j] : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < PXT; j++) {
-        const bool hit = nn[j] > 0;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
-        if (bal) {
-            const int leader = __builtin_ctzll(bal);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&s_total, (int)__popcll(bal));
-            base = __builtin_amdgcn_readlane(base, leader);
-            if (hit) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (unsigned short)(j * 256 + t);
-        }
-    }
-    __syncthreads();
-    const int total = s_total;
-    for (int e = t; e < total; e += 256) {
-        const size_t i = i0 + s_list[e];
-        const int yp = (int)(i / (size_t)W), q = (int)(i % (size_t)W);
-        const size_t pidx = f * npf + i;
-        const int n = k.rcnt[pidx];
-        u32 ids[RLCAP];
-        r_load_list(k, pidx, ids); // independent of n: all three loads are in flight together
-        if (n <= RLCAP) {
-            r_replay_list(k, f, yp, q, pidx, n, ids);
-        } else { // overflowed list (typically column W-1, the wraparound target of every hint near the left border)
-            u8 *px = k.r + pidx * k.C;
-            u8 R[4] = {0, 0, 0, 0};
-            for (int j = 0; j < k.C; j++) R[j] = px[j];
-            r_chain(k, f, yp, q, R, H, 0x7FFFFFFF, 0x7FFFFFFF);
-            for (int j = 0; j < k.C; j++) px[j] = R[j];
-        }
-    }
-}
-
-// List build and replay of one R row in ONE block (frames narrow enough for the row's lists to sit in LDS).  The hints
-// that can touch row yp are those of rows yp - n .. yp + n: their (hint, target column) items append to the row's lists with
-// LDS atomics -- rlist_kernel's global ones, one L2 operation per item, were what bounded it --, the touched pixels are
-// compacted and replayed from LDS; no count image to clear, to fill and to read back, no lists through memory.
+// List build and replay of (a part of) one R row in ONE block, the lists in LDS.  The hints that can touch row yp are those
+// of rows yp - n .. yp + n: their (hint, target column) items append to the row's lists with LDS atomics -- as global
+// atomics, one L2 operation per item, they were what bounded the list kernel of rounds 1-3 (14 M per 16 frames) --, the
+// touched pixels are compacted and replayed from LDS; no count image to clear, to fill and to read back, no lists through
+// memory.
 // Only the second L pass (apply_l_heavy_kernel, apply_l_wide_kernel: r_chain) reads lists of R pixels, and only of pixels an
 // OCCLUDED hint writes (the two pixels it blends into, pyx:114-122) or of column W-1 (the unguarded read of pyx:119): with
 // `lists` those go to memory, and the count of every pixel of the row.
 // IDT: a list entry is (row offset << IB) | index in row: 16 bits when W <= 2048 (IB = 11), else 32 (IB = 16).
 // mode bit 0: replay, bit 1: write the lists out.
 template <typename IDT, int IB, int NT>
-__global__ void __launch_bounds__(NT) r_rows_kernel(VppK k, int mode)
+__global__ void __launch_bounds__(NT) r_rows_kernel(VppK k, int mode, int SW)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
     __shared__ int s_off[33];
-    __shared__ int s_total;
+    __shared__ int s_total, s_n2, s_n3;
     const int W = k.W, H = k.H, n = k.n;
-    const int yp = blockIdx.x, f = blockIdx.y;
+    // a block owns the columns [q0, q0 + SW) of row yp (SW = W, or a part of a row too wide for one block's LDS)
+    const int nseg = (W + SW - 1) / SW;
+    const int yp = blockIdx.x / nseg, q0 = (blockIdx.x % nseg) * SW, f = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63;
-    u32 *s_cnt = s_dyn;                                  // [W] low half: hints on the pixel, high half: occluded ones among them
-    IDT *s_list = (IDT *)(s_dyn + W);                    // [W][RLCAP]
-    unsigned short *s_touch = (unsigned short *)(s_list + (size_t)W * RLCAP); // [W] touched columns
+    u32 *s_cnt = s_dyn;                                  // [SW] low half: hints on the pixel, high half: occluded ones among them
+    IDT *s_list = (IDT *)(s_dyn + SW);                   // [SW][RLCAP]
+    // touched columns by list length: one entry from the front of [0, SW), three and more from its back, two in [SW, 2 SW) --
+    // replayed in that order, so that nearly every wave holds lists of one length
+    unsigned short *s_touch = (unsigned short *)(s_list + (size_t)SW * RLCAP);
     const int span = 2 * n + 1, tw = 2 * n + 2;          // source rows, columns of a hint's target range
-    for (int q = t; q < W; q += NT) s_cnt[q] = 0;
-    if (t == 0) s_total = 0;
+    for (int q = t; q < SW; q += NT) s_cnt[q] = 0;
+    if (t == 0) s_total = 0, s_n2 = 0, s_n3 = 0;
     if (t < 64) { // items per source row and their prefix (span <= 31)
         const int yy = yp - n + t;
         int c = (t < span && yy >= 0 && yy <= H - 1) ? k.row_count[(size_t)f * H + yy] * tw : 0;
@@ -889,6 +792,7 @@ __global__ void __launch_bounds__(NT) r_rows_kernel(VppK k, int mode)
     }
     __syncthreads();
     const int total_items = s_off[span];
+    const u32 tw_magic = 0xFFFFFFFFu / (u32)tw + 1u; // loc / tw == umulhi(loc, magic) for loc * tw < 2^32 (loc < 2^16 * 32)
     for (int t0 = t; t0 < total_items; t0 += NT * 4) {
         int rr[4], ii[4], tqv[4];
         u32 rgs[4], fl[4];
@@ -896,11 +800,11 @@ __global__ void __launch_bounds__(NT) r_rows_kernel(VppK k, int mode)
         for (int u = 0; u < 4; u++) {
             const int it = min(t0 + NT * u, total_items - 1);
             int r = 0;
-            while (r + 1 < span && s_off[r + 1] <= it) r++;
+            for (int j = 1; j < span; j++) r += s_off[j] <= it ? 1 : 0; // (s_off is non-decreasing)
             const int loc = it - s_off[r];
             rr[u] = r;
-            ii[u] = loc / tw;
-            tqv[u] = loc % tw;
+            ii[u] = (int)__umulhi((u32)loc, tw_magic);
+            tqv[u] = loc - ii[u] * tw;
             const size_t ro = ((size_t)f * H + (yp - n + r)) * W + ii[u];
             rgs[u] = k.rng[ro];
             fl[u] = k.rec[ro].flags;
@@ -912,45 +816,52 @@ __global__ void __launch_bounds__(NT) r_rows_kernel(VppK k, int mode)
             const u32 add = 1u + ((fl[u] & 1u) << 16);
             const IDT id = (IDT)(((u32)rr[u] << IB) | (u32)ii[u]);
             const int q = lo + tqv[u];
-            if (q >= 0 && q <= hi && q <= W - 1) {
-                const u32 slot = atomicAdd(&s_cnt[q], add) & 0xFFFFu;
-                if (slot < RLCAP) s_list[(size_t)q * RLCAP + slot] = id;
+            if (q >= 0 && q <= hi && q <= W - 1 && q >= q0 && q < q0 + SW) {
+                const u32 slot = atomicAdd(&s_cnt[q - q0], add) & 0xFFFFu;
+                if (slot < RLCAP) s_list[(size_t)(q - q0) * RLCAP + slot] = id;
             }
             // Python-style wraparound target, column W-1 (SURVEY C-1/C-2): only the un-interpolated write
             // r[.., xd+xw] with xd = xd0-1 and xd0+xw == 0 can index -1 (pyx:113,121), i.e. lo < 0 <= hi
-            if (tqv[u] == 0 && !k.interp && lo < 0 && hi >= 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi)) {
-                const u32 slot = atomicAdd(&s_cnt[W - 1], add) & 0xFFFFu;
-                if (slot < RLCAP) s_list[(size_t)(W - 1) * RLCAP + slot] = id;
+            if (tqv[u] == 0 && !k.interp && lo < 0 && hi >= 0 && !(W - 1 >= max(lo, 0) && W - 1 <= hi) && W - 1 < q0 + SW) {
+                const u32 slot = atomicAdd(&s_cnt[W - 1 - q0], add) & 0xFFFFu;
+                if (slot < RLCAP) s_list[(size_t)(W - 1 - q0) * RLCAP + slot] = id;
             }
         }
     }
     __syncthreads();
     const size_t prow = ((size_t)f * H + yp) * W;
-    for (int qb = t & ~63; qb < W; qb += NT) { // (whole waves)
+    for (int qb = t & ~63; qb < SW; qb += NT) { // (whole waves; q is the column inside the block's part of the row)
         const int q = qb + lane;
-        const u32 c = q < W ? s_cnt[q] : 0u;
-        if ((mode & 2) && q < W) k.rcnt[prow + q] = (int)(c & 0xFFFFu);
-        const bool hit = (c & 0xFFFFu) != 0;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
-        if (bal) {
-            const int leader = __builtin_ctzll(bal);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&s_total, (int)__popcll(bal));
-            base = __builtin_amdgcn_readlane(base, leader);
-            if (hit) s_touch[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (unsigned short)q;
+        const bool qin = q < SW && q0 + q < W;
+        const u32 c = qin ? s_cnt[q] : 0u;
+        if ((mode & 2) && qin) k.rcnt[prow + q0 + q] = (int)(c & 0xFFFFu);
+        const u32 cn = c & 0xFFFFu;
+#pragma unroll
+        for (int cls = 0; cls < 3; cls++) {
+            const bool hit = cls == 0 ? cn == 1 : (cls == 1 ? cn == 2 : cn > 2);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            if (bal) {
+                const int leader = __builtin_ctzll(bal);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(cls == 0 ? &s_total : (cls == 1 ? &s_n2 : &s_n3), (int)__popcll(bal));
+                base = __builtin_amdgcn_readlane(base, leader);
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                if (hit) s_touch[cls == 0 ? slot : (cls == 1 ? SW + slot : SW - 1 - slot)] = (unsigned short)q;
+            }
         }
     }
     __syncthreads();
-    const int total = s_total;
+    const int n1 = s_total, n2 = s_n2, total = n1 + n2 + s_n3;
     for (int e = t; e < total; e += NT) {
-        const int q = s_touch[e];
-        const u32 c = s_cnt[q];
+        const int ql = s_touch[e < n1 ? e : (e < n1 + n2 ? SW + (e - n1) : SW - 1 - (e - n1 - n2))];
+        const u32 c = s_cnt[ql];
         const int cnt = (int)(c & 0xFFFFu);
+        const int q = q0 + ql;
         const size_t pidx = prow + q;
         u32 ids[RLCAP];
 #pragma unroll
         for (int i = 0; i < RLCAP; i++) {
-            const u32 pk = (u32)s_list[(size_t)q * RLCAP + i];
+            const u32 pk = (u32)s_list[(size_t)ql * RLCAP + i];
             ids[i] = ((u32)(yp - n + (int)(pk >> IB)) << 16) | (pk & ((1u << IB) - 1u));
         }
         if ((mode & 2) && ((c >> 16) != 0 || q == W - 1)) {
@@ -971,10 +882,10 @@ __global__ void __launch_bounds__(NT) r_rows_kernel(VppK k, int mode)
     }
 }
 #define RR_NT 256 // (192 .. 256 threads per row measure the same, 320 and more lose a third)
-static size_t r_rows_lds(int W, bool wide_ids) { return (size_t)W * (4 + RLCAP * (wide_ids ? 4 : 2) + 2) + 16; }
+static size_t r_rows_lds(int W, bool wide_ids) { return (size_t)W * (4 + RLCAP * (wide_ids ? 4 : 2) + 4) + 16; }
 
 // ---------------------------------------------------------------------------------------
-// 4. L pixels (they replay R chains from the ORIGINAL right image: before apply_r_px_kernel unless the caller kept a copy)
+// 4. L pixels (they replay R chains from the ORIGINAL right image: before the R replay unless the caller kept a copy)
 // ---------------------------------------------------------------------------------------
 // one hint at (yy, xx) acting on L pixel (yp, xp)
 // `defer` != nullptr: the caller cannot afford the occluded-hint branch (it replays R sub-chains: ten times the work of a
@@ -1923,7 +1834,8 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         k.rnd = nullptr;
         k.rnd_cap = 0;
         k.uniform = 1; // no random draws: keeps the draw bookkeeping of compact_kernel trivial
-        compact_kernel<<<dim3((g.H + 3) / 4, g.B), 256, 0, ctx->stream>>>(k);
+        if (k.use_dist) compact_kernel<true><<<dim3((g.H + 3) / 4, g.B), 256, 0, ctx->stream>>>(k);
+        else compact_kernel<false><<<dim3((g.H + 3) / 4, g.B), 256, 0, ctx->stream>>>(k);
         VPPX_CHECK_LAUNCH();
         rowscan_kernel<<<dim3(g.B), 256, 0, ctx->stream>>>(k, (long long *)n_hints_dev);
         VPPX_CHECK_LAUNCH();
@@ -1966,7 +1878,8 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     if ((rc = ws_get(ctx, WS_LWORK, npx * 2, &k.lwork))) return rc; // (a pixel is deferred at most once)
     if ((rc = ws_get(ctx, WS_LWORK_CNT, (size_t)4, &k.lwork_cnt))) return rc;
 
-    compact_kernel<<<dim3((g.H + 3) / 4, g.B), 256, 0, ctx->stream>>>(k);
+    if (k.use_dist) compact_kernel<true><<<dim3((g.H + 3) / 4, g.B), 256, 0, ctx->stream>>>(k);
+        else compact_kernel<false><<<dim3((g.H + 3) / 4, g.B), 256, 0, ctx->stream>>>(k);
     VPPX_CHECK_LAUNCH();
     rowscan_kernel<<<dim3(g.B), 256, 0, ctx->stream>>>(k, (long long *)n_hints_dev);
     VPPX_CHECK_LAUNCH();
@@ -2016,34 +1929,17 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         default: apply_l_heavy_kernel<7><<<hg, 64, 0, st>>>(k); break;
         }
     };
-    // R rows in LDS (r_rows_kernel) where a row's lists fit, else lists through memory (rlist_kernel + apply_r_px_kernel)
+    // R side: r_rows_kernel, a block per row of up to 2048 columns (45 KB of LDS with 16-bit list entries), per part of at
+    // most 1024 columns (39 KB with 32-bit entries) of a wider one.  (Parts of 512 columns, 11 KB, so that three blocks fit a CU next to the sum / WTA
+    // kernel: 135 -> 179 us per 16 frames alone, 312 -> 611 us in the step -- every part walks all the hints of its rows.)
     const bool wide_ids = g.W > 2048;
-    const size_t rows_lds = r_rows_lds(g.W, wide_ids);
-    const bool r_rows = rows_lds <= 128 * 1024;
-    if (r_rows && rows_lds > 48 * 1024) {
-        static bool attr_set[VPPX_MAX_DEVICES][2] = {};
-        if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)][wide_ids]) {
-            if (wide_ids) VPPX_HIP(hipFuncSetAttribute((const void *)r_rows_kernel<u32, 16, RR_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            else VPPX_HIP(hipFuncSetAttribute((const void *)r_rows_kernel<unsigned short, 11, RR_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)][wide_ids] = true;
-        }
-    }
+    const int rr_nseg = wide_ids ? (g.W + 1023) / 1024 : 1, rr_sw = (g.W + rr_nseg - 1) / rr_nseg;
+    const size_t rows_lds = r_rows_lds(rr_sw, wide_ids);
     const bool need_lists = occ != nullptr && !k.discard; // some L kernel replays R sub-chains (r_chain)
     if (!need_lists) k.rcnt = nullptr;
     auto launch_r_rows = [&](int mode) {
-        if (wide_ids) r_rows_kernel<u32, 16, RR_NT><<<dim3(g.H, g.B), RR_NT, rows_lds, ctx->stream>>>(k, mode);
-        else r_rows_kernel<unsigned short, 11, RR_NT><<<dim3(g.H, g.B), RR_NT, rows_lds, ctx->stream>>>(k, mode);
-    };
-    auto launch_r_lists = [&]() -> int { // lists through memory
-        VPPX_HIP(hipMemsetAsync(k.rcnt, 0, npx * sizeof(int), ctx->stream));
-        rlist_kernel<<<dim3(g.H, g.B), 256, 0, ctx->stream>>>(k);
-        VPPX_CHECK_LAUNCH();
-        return 0;
-    };
-    auto launch_r_px = [&]() {
-        const size_t npf = (size_t)g.H * g.W;
-        if (npf * g.B >= (size_t)4096 * 1024) apply_r_px_kernel<16><<<dim3((unsigned)((npf + 4095) / 4096), g.B), 256, 0, ctx->stream>>>(k);
-        else apply_r_px_kernel<4><<<dim3((unsigned)((npf + 1023) / 1024), g.B), 256, 0, ctx->stream>>>(k);
+        if (wide_ids) r_rows_kernel<u32, 16, RR_NT><<<dim3(g.H * rr_nseg, g.B), RR_NT, rows_lds, ctx->stream>>>(k, mode, rr_sw);
+        else r_rows_kernel<unsigned short, 11, RR_NT><<<dim3(g.H * rr_nseg, g.B), RR_NT, rows_lds, ctx->stream>>>(k, mode, rr_sw);
     };
     hipStream_t ls = ctx->stream;
     if (split) { // the L side on the side stream from here on
@@ -2057,14 +1953,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         VPPX_CHECK_LAUNCH();
         if (k.n > 3) apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k);
         VPPX_CHECK_LAUNCH();
-        if (r_rows) {
-            launch_r_rows(1);
-        } else {
-            k.rcnt = nullptr;
-            if ((rc = ws_get(ctx, WS_RCNT, npx, &k.rcnt))) return rc;
-            if ((rc = launch_r_lists())) return rc;
-            launch_r_px();
-        }
+        launch_r_rows(1);
         VPPX_CHECK_LAUNCH();
     } else if (split_late) {
         // the caller kept the original right image: the R side runs right away (building the lists as it goes), the first
@@ -2073,31 +1962,23 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
             launch_l_hint(ls);
             VPPX_CHECK_LAUNCH();
         }
-        if (r_rows) {
-            launch_r_rows(3);
-        } else {
-            if ((rc = launch_r_lists())) return rc;
-        }
+        launch_r_rows(3);
         VPPX_CHECK_LAUNCH();
         VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         VPPX_HIP(hipStreamWaitEvent(ls, ctx->ev_fork, 0));
-        if (!r_rows) launch_r_px();
-        VPPX_CHECK_LAUNCH();
         if (two_pass) launch_l_heavy(ls);
         else apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k); // (n > 3)
         VPPX_CHECK_LAUNCH();
     } else {
         // R is patterned in place: every L pass that reads it comes first
-        if (r_rows) launch_r_rows(2);
-        else if ((rc = launch_r_lists())) return rc;
+        launch_r_rows(2);
         VPPX_CHECK_LAUNCH();
         launch_l_hint(ls);
         VPPX_CHECK_LAUNCH();
         if (two_pass) launch_l_heavy(ls);
         if (k.n > 3) apply_l_wide_kernel<<<grid, 256, 0, ls>>>(k);
         VPPX_CHECK_LAUNCH();
-        if (r_rows) launch_r_rows(1);
-        else launch_r_px();
+        launch_r_rows(1);
         VPPX_CHECK_LAUNCH();
     }
     if (split) {
@@ -2185,6 +2066,23 @@ int vpp_launch_rand_stream(vppx_ctx *ctx, u32 seed, u64 offset, int64_t n, int32
 // ---------------------------------------------------------------------------------------
 // occlusion heuristic (filter.py:246-292) -> conf map (the g_occ of test.py:154)
 // ---------------------------------------------------------------------------------------
+// (four pixels per thread where rows are 16-byte aligned: a quarter of the waves for the same loads)
+__global__ void __launch_bounds__(256) occ_warp4_kernel(const float4 *__restrict__ dmap, int *__restrict__ omap_bits, int H, int W)
+{
+    const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (4 * x4 >= W) return;
+    const size_t row = ((size_t)f * H + y) * W;
+    const float4 q = dmap[row / 4 + x4];
+    const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (v[j] > 0) {
+            const int xd = 4 * x4 + j - (int)rintf(v[j]);
+            if (0 <= xd && xd <= W - 1) atomicMax(&omap_bits[row + xd], __float_as_int(v[j])); // positive floats order as ints
+        }
+    }
+}
 __global__ void __launch_bounds__(256) occ_warp_kernel(const float *__restrict__ dmap, int *__restrict__ omap_bits, int H, int W)
 {
     // left_warp (filter.py:8-48): omap[y, x-round(d)] keeps the max on collision
@@ -2381,7 +2279,10 @@ int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, i
         if (rc) return rc;
     }
     VPPX_HIP(hipMemsetAsync(omap, 0, n * sizeof(float), ctx->stream));
-    occ_warp_kernel<<<grid, 256, 0, ctx->stream>>>(hints, (int *)omap, H, W);
+    if (W % 4 == 0 && ((size_t)hints & 15) == 0)
+        occ_warp4_kernel<<<dim3((W / 4 + 255) / 256, H, B), 256, 0, ctx->stream>>>((const float4 *)hints, (int *)omap, H, W);
+    else
+        occ_warp_kernel<<<grid, 256, 0, ctx->stream>>>(hints, (int *)omap, H, W);
     VPPX_CHECK_LAUNCH();
     rx /= 2, ry /= 2; // filter.py:142-143
     const long long nwin = (2LL * rx + 1) * (2LL * ry + 2);
