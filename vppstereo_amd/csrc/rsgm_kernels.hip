@@ -2284,7 +2284,15 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     a.spin_limit = ctx->v3.spin_limit;
     a.serial = ++ctx->v3.serial;
     if (a.serial == 0) a.serial = ++ctx->v3.serial;
-    VPPX_HIP(hipMemsetAsync(xbuf, 0, rsgm_vert3_xbuf_bytes(B, Wp, D), stream)); // no record of an earlier launch may match
+    // no record of an earlier launch may match: cleared here, unless a pipelined call's front_end has already queued the
+    // clear on this stream behind the previous launch (vppx_api.hip; never inside a graph capture: a replayed graph must
+    // carry its own clear)
+    const size_t xbytes = rsgm_vert3_xbuf_bytes(B, Wp, D);
+    if (!(ctx->xbuf_cleared && !ctx->capturing && ctx->xbuf_last == (void *)xbuf && ctx->xbuf_last_bytes >= xbytes && stream == ctx->stream))
+        VPPX_HIP(hipMemsetAsync(xbuf, 0, xbytes, stream));
+    ctx->xbuf_last = (void *)xbuf;
+    ctx->xbuf_last_bytes = xbytes;
+    ctx->xbuf_cleared = false;
     const dim3 grid((unsigned)((2 * B + 7) / 8 * 8 * a.nbg)); // whole rounds of 8 groups; groups >= 2B exit at once
     if (wide && D == 64) sgm_vert4_kernel<16><<<grid, 256, 0, stream>>>(a);
     else if (wide && D == 128) sgm_vert4_kernel<32><<<grid, 256, 0, stream>>>(a);

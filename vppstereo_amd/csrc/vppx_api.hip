@@ -216,6 +216,7 @@ extern "C" void vppx_destroy(vppx_ctx *ctx)
     if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
     if (ctx->ev_agg_done) (void)hipEventDestroy(ctx->ev_agg_done);
     if (ctx->ev_front_done) (void)hipEventDestroy(ctx->ev_front_done);
+    if (ctx->ev_occ_done) (void)hipEventDestroy(ctx->ev_occ_done);
     if (ctx->ev_inputs_auto) (void)hipEventDestroy(ctx->ev_inputs_auto);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -841,12 +842,29 @@ static int front_end(vppx_ctx *ctx)
     ctx->stream = ctx->main_saved;
     ctx->front_active = false;
     VPPX_HIP(hipEventRecord(ctx->ev_front_done, front));
-    VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_front_done, 0));
+    // While the launch stream would only wait for the tail of the front stage, it does what does not need that tail: the
+    // exchange records of the next lock-step launch are cleared (behind the last one, which is queued on this stream), and
+    // the occlusion mask goes to the caller as soon as the occlusion stage is through.
+    if (ctx->xbuf_last && !ctx->xbuf_cleared && ctx->xbuf_last == ctx->ws[WS_VSTATE].p) { // (still the live workspace buffer)
+        VPPX_HIP(hipMemsetAsync(ctx->xbuf_last, 0, ctx->xbuf_last_bytes, ctx->stream));
+        ctx->xbuf_cleared = true;
+    }
     // what the caller wanted of the front stage's results, delivered in launch-stream order (and before this call's
     // aggregation, whose completion releases the library-owned buffers to the next front stage)
+    if (ctx->occ_done_recorded) {
+        bool any = false;
+        for (int i = 0; i < ctx->n_pipe_copy; i++) any = any || ctx->pipe_copy[i].early;
+        if (any) VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_occ_done, 0));
+        for (int i = 0; i < ctx->n_pipe_copy; i++)
+            if (ctx->pipe_copy[i].early)
+                VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    VPPX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_front_done, 0));
     for (int i = 0; i < ctx->n_pipe_copy; i++)
-        VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!(ctx->occ_done_recorded && ctx->pipe_copy[i].early))
+            VPPX_HIP(hipMemcpyAsync(ctx->pipe_copy[i].dst, ctx->pipe_copy[i].src, ctx->pipe_copy[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_pipe_copy = 0;
+    ctx->occ_done_recorded = false;
     if (ctx->pipe_call && ctx->pipe_early) {
         // Few frames per call: the aggregation is a handful of long dependent chains that leave most of the GPU idle, so
         // the NEXT call's front stage may start right now, next to it.  From here on nothing of this call reads what a front
@@ -868,6 +886,7 @@ struct FrontGuard { // error paths: never leave the context on the front stream
         }
         ctx->pipe_call = false;
         ctx->n_pipe_copy = 0;
+        ctx->occ_done_recorded = false;
     }
 };
 
@@ -1216,15 +1235,21 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
     if (piped) {
         ctx->pipe_call = true;
         if ((rc = front_begin(ctx))) return rc;
-        if (op && conf_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {conf_user, conf, np};
-        if (l_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {l_user, l_vpp, nb};
-        if (r_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {r_user, r_vpp, nb};
+        ctx->occ_done_recorded = false;
+        if (op && conf_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {conf_user, conf, np, true};
+        if (l_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {l_user, l_vpp, nb, false};
+        if (r_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {r_user, r_vpp, nb, false};
     }
     stage_begin(ctx);
     if (op) { // test.py:154: g_occ = occlusion_heuristic(hints)[1]
         if ((rc = occ_launch(ctx, B, H, W, g, op->rx, op->ry, op->l, op->g, op->th_conf, op->th_filter, omap, conf))) return rc;
         stage_mark(ctx, ST_OCC);
         g_occ = conf;
+        if (piped && conf_user) { // (front_end: the mask's copy to the caller waits for this, not for the whole front stage)
+            if (!ctx->ev_occ_done) VPPX_HIP(hipEventCreateWithFlags(&ctx->ev_occ_done, hipEventDisableTiming));
+            VPPX_HIP(hipEventRecord(ctx->ev_occ_done, ctx->stream));
+            ctx->occ_done_recorded = true;
+        }
     }
     // vpp() works on copies (np.copy, vpp_standalone.py:397)
     VPPX_HIP(hipMemcpyAsync(l_vpp, left, nb, hipMemcpyDeviceToDevice, ctx->stream));

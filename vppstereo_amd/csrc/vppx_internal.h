@@ -140,8 +140,13 @@ struct vppx_ctx {
     void *inputs_ev = nullptr;     // caller's "inputs of the next call are ready" event (vppx_inputs_ready_event), one-shot
     // front-stage results the caller asked for (mask, patterned pair): computed into library-owned buffers on the front
     // stream, copied to the caller's memory on the LAUNCH stream once it has waited for the front stage
-    struct PipeCopy { void *dst; const void *src; size_t bytes; } pipe_copy[3];
+    struct PipeCopy { void *dst; const void *src; size_t bytes; bool early; } pipe_copy[3]; // early: ready at ev_occ_done already
     int n_pipe_copy = 0;
+    hipEvent_t ev_occ_done = nullptr;   // front stream: the occlusion mask of the call is complete
+    bool occ_done_recorded = false;
+    void *xbuf_last = nullptr;          // exchange records of the last lock-step launch ...
+    size_t xbuf_last_bytes = 0;
+    bool xbuf_cleared = false;          // ... and whether a clear of them is already queued on the launch stream behind it
     unsigned *vert3_err = nullptr; // pinned host word the fused vertical kernel sets (to its launch serial) when a wave gave up waiting
     bool vert3_broken = false;     // the XCD / residency probe failed on this device: the context never uses the fused layout
     int vert3_rest = 0;            // aggregations left on the line-parallel layout after a lost lock step, before the fused layout is tried again
