@@ -1140,7 +1140,7 @@ __device__ __forceinline__ unsigned long long lb_mask(const unsigned long long (
     for (int wa = 0; wa < NWIN; wa++) mask |= (unsigned long long)lb_row_bits<NWIN>(s_w, r + wa, c, lane) << (wa * NWIN);
     return mask;
 }
-template <int NWIN, int ROWS, bool LIGHT>
+template <int NWIN, int ROWS>
 __global__ void __launch_bounds__(256) apply_l_bits_kernel(VppK k)
 {
     constexpr int n = (NWIN - 1) / 2;
@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(256) apply_l_bits_kernel(VppK k)
         const int yp = y0 + r, p = c0 * 64 + pp;
         const int xp = k.direction ? p : W - 1 - p;
         unsigned long long mask = lb_mask<NWIN>(s_w, r, pp >> 6, pp & 63);
-        const bool dfr = !l_replay_pixel<NWIN, LIGHT>(k, f, yp, xp, mask, nullptr, rnd_f, may_defer);
+        const bool dfr = !l_replay_pixel<NWIN, true>(k, f, yp, xp, mask, nullptr, rnd_f, may_defer);
         // deferred pixels: collected in LDS (in place: slot <= e, and every entry up to e has been consumed), one LDS atomic
         // per wave; the block then takes its share of the global work list with ONE atomic (atomics on a single address
         // queue up in one L2 channel: one per wave and round made them the longest part of this kernel)
@@ -1907,11 +1907,11 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     auto launch_l_hint = [&](hipStream_t st) {
         if (k.n > 3) return; // (apply_l_wide_kernel below)
         // rows per block: four, so that the touched pixels fill whole rounds of the block's replay; one when a call has too few
-        // rows to give every CU a block otherwise.  With two passes the first one has no code for occluded hints at all.
+        // rows to give every CU a block otherwise.  The kernel has no code for occluded hints at all: it defers them
+        // (with a mask that does not discard them: two_pass), and otherwise there are none to act on.
         const bool r4 = (long long)g.B * g.H >= 4 * 1024;
         const dim3 bg((unsigned)((g.W + 1023) / 1024), (unsigned)(r4 ? (g.H + 3) / 4 : g.H), (unsigned)g.B);
-#define LB(NW) do { if (two_pass && r4) apply_l_bits_kernel<NW, 4, true><<<bg, 256, 0, st>>>(k); else if (two_pass) apply_l_bits_kernel<NW, 1, true><<<bg, 256, 0, st>>>(k); \
-                    else if (r4) apply_l_bits_kernel<NW, 4, false><<<bg, 256, 0, st>>>(k); else apply_l_bits_kernel<NW, 1, false><<<bg, 256, 0, st>>>(k); } while (0)
+#define LB(NW) do { if (r4) apply_l_bits_kernel<NW, 4><<<bg, 256, 0, st>>>(k); else apply_l_bits_kernel<NW, 1><<<bg, 256, 0, st>>>(k); } while (0)
         switch (k.n) {
         case 0: LB(1); break;
         case 1: LB(3); break;
