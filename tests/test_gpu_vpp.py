@@ -233,12 +233,13 @@ def test_occlusion_heuristic_returns_the_references_pair():
         d[m] = (rng.integers(8, 80, int(m.sum())) * 0.125).astype(np.float32)   # small disparities: many land next to each other
         d[h // 3: 2 * h // 3, w // 3: w // 2][d[h // 3: 2 * h // 3, w // 3: w // 2] > 0] += 9.0
         d[:, 0] = np.where(rng.random(h) < 0.5, 0, d[:, 0])       # zeros and values in the border columns
-        want_d, want_c = oracle.occlusion_heuristic(d)
-        got_d, got_c = vfilter.occlusion_heuristic(d)
-        assert got_d.dtype == np.float32 and got_d.shape == d.shape
-        assert np.array_equal(got_c, want_c), i
-        assert np.array_equal(got_d, want_d), (i, int((got_d != want_d).sum()))
-        assert (want_d != 0).any()
+        for kw in (dict(), dict(th_conf=0.5, th_filter=1.5)): # (the second: rejected pixels survive the filter)
+            want_d, want_c = oracle.occlusion_heuristic(d, **kw)
+            got_d, got_c = vfilter.occlusion_heuristic(d, **kw)
+            assert got_d.dtype == np.float32 and got_d.shape == d.shape
+            assert np.array_equal(got_c, want_c), (i, kw)
+            assert np.array_equal(got_d, want_d), (i, kw, int((got_d != want_d).sum()))
+            assert (want_d != 0).any()
     filled = 0
     for _ in range(3):   # dense small maps: the interpolation actually fills something, also across the row ends
         d = (rng.integers(0, 3, (12, 20)) * rng.integers(8, 12, (12, 20)) * 0.125).astype(np.float32)
@@ -315,17 +316,20 @@ def test_mixed_density_batch_uses_both_thread_mappings(kw):
         assert np.array_equal(b0, rg[f]), (f, dens[f], kw)
 
 
-@pytest.mark.parametrize("h,w,p", [(61, 97, 0.05), (135, 240, 0.03), (8, 8, 0.5), (40, 700, 0.3), (270, 480, 0.01)])
+@pytest.mark.parametrize("h,w,p", [(61, 97, 0.05), (135, 240, 0.03), (8, 8, 0.5), (40, 700, 0.3), (270, 480, 0.01), (12, 1300, 0.05)])
 def test_occlusion_mask_single_launch_kernel(h, w, p):
-    """The mask alone (Engine.occlusion_heuristic, what the hot path takes: occ_rows_kernel, rows in LDS) against the oracle,
-    default and other window / weight / threshold parameters, dense and sparse hints, several frames per call."""
+    """The mask alone (Engine.occlusion_heuristic, what the hot path takes: occ_warp(4)_kernel + occ_test_kernel) against the
+    oracle: default and other window / weight / threshold parameters -- windows of 2 to 420 positions, i.e. one to four
+    positions per lane and the general loop; a filter threshold that keeps rejected pixels --, dense and sparse hints, rows
+    wider than one block, widths that are no multiple of four, several frames per call."""
     import torch
     from vppstereo_amd.engine import Engine
     eng = Engine()
     b = synth.make_batch(3, h, w, 64, p, seed=h + w)
     hints = torch.from_numpy(np.ascontiguousarray(b["hints"])).to(eng.device)
     for kw in (dict(), dict(rx=5, ry=3), dict(rx=13, ry=11, l=1.5, g=0.3), dict(rx=1, ry=1), dict(th_conf=0.25, th_filter=0.1),
-               dict(rx=9, ry=7, l=0.5, g=0.9, th_conf=2)):
+               dict(rx=9, ry=7, l=0.5, g=0.9, th_conf=2), dict(rx=17, ry=13, l=0.7), dict(rx=21, ry=19, l=0.4, g=0.5),
+               dict(th_conf=0.5, th_filter=1.5)):
         got = eng.occlusion_heuristic(hints, **kw).cpu().numpy()
         for f in range(3):
             want = oracle.occlusion_heuristic(b["hints"][f], **kw)[1]
