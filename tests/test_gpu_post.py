@@ -161,3 +161,26 @@ def test_headline_size_random_regions(eng):
     rng = np.random.default_rng(77)
     h, w = 540, 960
     _run(eng, [_blocks(h, w, rng, 4, 30), _blocks(h, w, rng, 8, 24)], h, w, rng)
+
+
+@pytest.mark.parametrize("h,w", [(70, 130), (40, 300)])
+def test_background_interpolation_with_empty_rows_and_frames(eng, h, w):
+    """_interpolate_background (rsgm.py:185-227): rows without any valid disparity at the top and at the bottom take the
+    first / last non-empty row (the column pass works from per-row flags: after the row pass a row is valid everywhere or
+    nowhere), empty rows in between stay empty, an entirely empty frame stays empty, one valid pixel fills its row and,
+    through the column pass, the whole frame; large regions so that the speckle filter keeps them."""
+    rng = np.random.default_rng(h + w)
+    maps = []
+    m = _blocks(h, w, rng, 20, 40)
+    m[:5] = 0
+    m[h - 3:] = 0
+    m[h // 2: h // 2 + 2] = 0          # empty rows in the middle: unchanged by both passes
+    maps.append(m)
+    maps.append(np.zeros((h, w), np.float32))
+    m = np.zeros((h, w), np.float32)
+    m[h // 3: h // 3 + 18, w // 4: w // 4 + 18] = 37.5   # one block of 324 pixels in the middle of nothing
+    maps.append(m)
+    m = _blocks(h, w, rng, 20, 40)
+    m[1:] = np.where(rng.random((h - 1, w)) < 0.5, 0, m[1:])  # noise (mostly removed as speckles) under a full first row
+    maps.append(m)
+    _run(eng, maps, h, w, rng, True, flip=0.0)
