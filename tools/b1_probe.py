@@ -1,3 +1,6 @@
+"""tools/b1_probe.py: 40 pipelined single-pair calls (540x960x192, occlusion heuristic + VPP + rSGM, inputs resident) for a
+kernel trace of the steady state: rocprofv3 --kernel-trace ... -- python3 tools/b1_probe.py, then tools/b1_sum.py <trace csv>
+prints one period (from one 8-path aggregation launch to the next)."""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch

@@ -1,3 +1,5 @@
+"""tools/b1_sum.py <kernel_trace.csv>: the launches between the 21st and the 22nd 8-path aggregation launch of a trace of
+tools/b1_probe.py: start offset, duration, kernel, queue."""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "sgm_paths_kernel" in r["Kernel_Name"]]
