@@ -12,7 +12,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 H, W, D = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (540, 960, 192)
 eng = Engine()
 nu = min(B, 8)
-b = synth.make_batch(nu, H, W, D, 0.03, seed=1234)
+b = synth.make_batch(nu, H, W, D, float(os.environ.get("PROBE_DENSITY", "0.03")), seed=1234)
 idx = [i % nu for i in range(B)]
 l, r, h = (torch.from_numpy(np.ascontiguousarray(b[k][idx])).to(eng.device) for k in ("left", "right", "hints"))
 out = torch.empty((B, H, W), dtype=torch.float32, device=eng.device)

@@ -2939,6 +2939,15 @@ static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
     return launch_lr_t<16, IT, NV, 32, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub, sw4); // D = 256: 153 KiB
 }
 
+// LDS of one block of the fused sum / WTA kernel (its tile ring; launch_lr_d / launch_lr_t2): what a kernel that runs next to it
+// cannot have
+size_t rsgm_sum_lds_bytes(int D)
+{
+    const int T = D == 256 ? 32 : 64;
+    const int NT = (T + D - 2) / T + 1 + (D == 256 ? 0 : 1);
+    return ((size_t)NT * D * (T + 2) + T) * sizeof(u16);
+}
+
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
                            float *disp_l, float *disp_r, u32 fu, int sub, int max_path_value)
 {

@@ -1909,7 +1909,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         // rows per block: four, so that the touched pixels fill whole rounds of the block's replay; one when a call has too few
         // rows to give every CU a block otherwise.  The kernel has no code for occluded hints at all: it defers them
         // (with a mask that does not discard them: two_pass), and otherwise there are none to act on.
-        const bool r4 = (long long)g.B * g.H >= 4 * 1024;
+        const bool r4 = (long long)g.B * g.H >= 4 * 1024 && ctx->front_lds_budget >= 18 * 1024; // (17 KB of LDS against 4.5)
         const dim3 bg((unsigned)((g.W + 1023) / 1024), (unsigned)(r4 ? (g.H + 3) / 4 : g.H), (unsigned)g.B);
 #define LB(NW) do { if (r4) apply_l_bits_kernel<NW, 4><<<bg, 256, 0, st>>>(k); else apply_l_bits_kernel<NW, 1><<<bg, 256, 0, st>>>(k); } while (0)
         switch (k.n) {
@@ -1933,7 +1933,13 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     // most 1024 columns (39 KB with 32-bit entries) of a wider one.  (Parts of 512 columns, 11 KB, so that three blocks fit a CU next to the sum / WTA
     // kernel: 135 -> 179 us per 16 frames alone, 312 -> 611 us in the step -- every part walks all the hints of its rows.)
     const bool wide_ids = g.W > 2048;
-    const int rr_nseg = wide_ids ? (g.W + 1023) / 1024 : 1, rr_sw = (g.W + rr_nseg - 1) / rr_nseg;
+    int rr_nseg = wide_ids ? (g.W + 1023) / 1024 : 1;
+    if (r_rows_lds((g.W + rr_nseg - 1) / rr_nseg, wide_ids) > ctx->front_lds_budget) { // parts that fit next to the sum / WTA kernel
+        const int per_col = 4 + RLCAP * (wide_ids ? 4 : 2) + 4;
+        const int sw_max = (int)((ctx->front_lds_budget > 2048 ? ctx->front_lds_budget - 512 : 1536) / per_col);
+        rr_nseg = (g.W + sw_max - 1) / sw_max;
+    }
+    const int rr_sw = (g.W + rr_nseg - 1) / rr_nseg;
     const size_t rows_lds = r_rows_lds(rr_sw, wide_ids);
     const bool need_lists = occ != nullptr && !k.discard; // some L kernel replays R sub-chains (r_chain)
     if (!need_lists) k.rcnt = nullptr;
@@ -2109,40 +2115,41 @@ __global__ void __launch_bounds__(256) occ_warp_kernel(const float *__restrict__
 // collects the owners in LDS, and its waves then take them four at a time and test all window positions of the four at
 // once, one per lane and NJ per owner; the loads are unconditional at clamped coordinates (hipcc does not speculate
 // loads: a conditional one costs a branch and a full wait each) so that all 4 NJ are in flight together.
-template <int NJ>
+// PT: pixels per thread (4: a block owns 1024 pixels and 11 KB of LDS; 2: 512 pixels, 5.6 KB)
+template <int NJ, int PT>
 __global__ void __launch_bounds__(256) occ_test_kernel(const float *__restrict__ hints, const float *__restrict__ omap,
                                                        u8 *__restrict__ out, int *__restrict__ tmp, int H, int W, int rx,
                                                        int ry, double l, double g, double th, double th_filter)
 {
-    __shared__ int s_xd[1024];
-    __shared__ float s_v[1024];
-    __shared__ unsigned short s_px[1024];
-    __shared__ u8 s_cf[1024];
+    __shared__ int s_xd[256 * PT];
+    __shared__ float s_v[256 * PT];
+    __shared__ unsigned short s_px[256 * PT];
+    __shared__ u8 s_cf[256 * PT];
     __shared__ int s_total;
-    const int x0 = blockIdx.x * 1024;
+    const int x0 = blockIdx.x * (256 * PT);
     const int y = blockIdx.y, f = blockIdx.z;
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const float *om = omap + (size_t)f * H * W;
     const size_t row = ((size_t)f * H + y) * W;
     if (t == 0) s_total = 0;
-    float v[4], at[4];
-    int xd[4];
+    float v[PT], at[PT];
+    int xd[PT];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < PT; u++) {
         const int x = x0 + 256 * u + t;
         v[u] = hints[row + min(x, W - 1)];
         if (x >= W) v[u] = 0.0f;
         s_cf[256 * u + t] = 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < PT; u++) {
         xd[u] = x0 + 256 * u + t - (int)rintf(v[u]);
         at[u] = om[(size_t)y * W + min(max(xd[u], 0), W - 1)];
     }
     __syncthreads();
-    bool owner[4];
+    bool owner[PT];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < PT; u++) {
         owner[u] = v[u] > 0 && 0 <= xd[u] && xd[u] <= W - 1 && at[u] == v[u];
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(owner[u]);
         if (bal) {
@@ -2226,7 +2233,7 @@ __global__ void __launch_bounds__(256) occ_test_kernel(const float *__restrict__
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < PT; u++) {
         const int x = x0 + 256 * u + t;
         if (x >= W) continue;
         const int cf = s_cf[256 * u + t];
@@ -2272,7 +2279,9 @@ int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, i
                double th_conf, double th_filter, float *omap, u8 *conf_out, float *dmap_out)
 {
     const size_t n = (size_t)B * H * W;
-    dim3 grid((W + 255) / 256, H, B), grid_t((W + 1023) / 1024, H, B);
+    // (next to a sum / WTA kernel that leaves less than 12 KB of LDS -- D = 256 -- the test kernel takes the 5.6 KB variant)
+    const bool small = ctx->front_lds_budget < 12 * 1024;
+    dim3 grid((W + 255) / 256, H, B), grid_t((W + (small ? 511 : 1023)) / (small ? 512 : 1024), H, B);
     int *tmp = nullptr;
     if (dmap_out) {
         int rc = ws_get(ctx, WS_OCC_TMP, n, &tmp);
@@ -2286,7 +2295,8 @@ int occ_launch(vppx_ctx *ctx, int B, int H, int W, const float *hints, int rx, i
     VPPX_CHECK_LAUNCH();
     rx /= 2, ry /= 2; // filter.py:142-143
     const long long nwin = (2LL * rx + 1) * (2LL * ry + 2);
-#define OCC_TEST(NJ) occ_test_kernel<NJ><<<grid_t, 256, 0, ctx->stream>>>(hints, omap, conf_out, tmp, H, W, rx, ry, l, g, th_conf, th_filter)
+#define OCC_TEST(NJ) do { if (small) occ_test_kernel<NJ, 2><<<grid_t, 256, 0, ctx->stream>>>(hints, omap, conf_out, tmp, H, W, rx, ry, l, g, th_conf, th_filter); \
+                          else occ_test_kernel<NJ, 4><<<grid_t, 256, 0, ctx->stream>>>(hints, omap, conf_out, tmp, H, W, rx, ry, l, g, th_conf, th_filter); } while (0)
     if (nwin <= 64) OCC_TEST(1);
     else if (nwin <= 128) OCC_TEST(2);
     else if (nwin <= 192) OCC_TEST(3);

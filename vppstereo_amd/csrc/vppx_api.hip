@@ -1081,6 +1081,7 @@ extern "C" int vppx_vpp_dev(vppx_ctx *ctx, const VppxVppParams *p, int B, int H,
         if ((rc = vpp_launch_bilateral_fill(ctx, *p, vg, l, g, fg))) return rc; // l is still un-patterned here
         filled_g = fg;
     }
+    ctx->front_lds_budget = 64 * 1024; // (no sum / WTA kernel of a previous part next to this)
     return vpp_launch(ctx, *p, vg, l, r, g, g_occ, filled_g, n_hints_dev, nullptr);
 }
 
@@ -1239,6 +1240,11 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
         if (op && conf_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {conf_user, conf, np, true};
         if (l_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {l_user, l_vpp, nb, false};
         if (r_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {r_user, r_vpp, nb, false};
+    }
+    {   // what the front-stage kernels may use of a CU's LDS: next to the previous part's sum / WTA kernel when pipelined
+        const size_t sum_lds = rsgm_sum_lds_bytes(rp->dmax), cu_lds = 160 * 1024;
+        const size_t left_over = cu_lds > sum_lds + 512 ? cu_lds - sum_lds - 512 : 2048;
+        ctx->front_lds_budget = (piped && left_over < 64 * 1024) ? left_over : 64 * 1024;
     }
     stage_begin(ctx);
     if (op) { // test.py:154: g_occ = occlusion_heuristic(hints)[1]
@@ -1587,6 +1593,7 @@ extern "C" int vppx_occlusion_heuristic_full_dev(vppx_ctx *ctx, int B, int H, in
     const size_t n = (size_t)B * H * W;
     float *omap;
     if ((rc = ws_get(ctx, WS_OCC_OMAP, n, &omap))) return rc;
+    ctx->front_lds_budget = 64 * 1024;
     return occ_launch(ctx, B, H, W, hints, rx, ry, l, g, th_conf, th_filter, omap, conf_out, dmap_out);
 }
 

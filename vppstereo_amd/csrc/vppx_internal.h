@@ -144,6 +144,10 @@ struct vppx_ctx {
     int n_pipe_copy = 0;
     hipEvent_t ev_occ_done = nullptr;   // front stream: the occlusion mask of the call is complete
     bool occ_done_recorded = false;
+    // LDS a front-stage kernel can count on per CU next to the sum / WTA kernel of the previous part or call, which holds
+    // one block per CU: 160 KB minus that kernel's tile ring (36 KB at D <= 192, 7 KB at D = 256).  Kernels pick block
+    // shapes that fit; set by the pipelined fused entry, "everything" otherwise.
+    size_t front_lds_budget = 64 * 1024;
     void *xbuf_last = nullptr;          // exchange records of the last lock-step launch ...
     size_t xbuf_last_bytes = 0;
     bool xbuf_cleared = false;          // ... and whether a clear of them is already queued on the launch stream behind it
@@ -294,6 +298,7 @@ int rsgm_launch_wta_right_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u
 int rsgm_paths_elem_bytes(int D, int maxp2);
 // fused sum + left/right WTA; returns 1 (not an error) when the shape is not covered
 // max_path_value: upper bound of one path value (Cmax + P2max); 0 = unknown
+size_t rsgm_sum_lds_bytes(int D);
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
                            float *disp_l, float *disp_r, u32 factor_uniq, int do_subpixel, int max_path_value);
 int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
