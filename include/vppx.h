@@ -209,8 +209,10 @@ int vppx_vpp_host(vppx_ctx *ctx, const VppxVppParams *p, int B, int H, int W, in
 int vppx_vpp_dev(vppx_ctx *ctx, const VppxVppParams *p, int B, int H, int W, int C, uint8_t *l, uint8_t *r,
                  const float *g, const uint8_t *g_occ, const float *filled_g, int64_t *n_hints_dev);
 
-/* Number of rand() draws each frame of the last vppx_vpp_* call consumed (host array [B]);
- * synchronises the stream.  Lets a caller continue the libc-like stream across calls. */
+/* Number of rand() draws each frame of the last vppx_vpp_host / vppx_vpp_dev call consumed (host array [B]);
+ * synchronises the stream.  Lets a caller continue the libc-like stream across calls.  Not defined after the fused
+ * entry points (vppx_vpp_rsgm_dev / vppx_occ_vpp_rsgm_dev): those may run a batch in parts (vppx_last_call_parts) and keep
+ * the counts of the last part only; their frames draw from srand(seed + frame) and never continue a stream. */
 int vppx_vpp_last_draws(vppx_ctx *ctx, int B, uint64_t *draws);
 
 /* ---- rSGM: pyrSGM-compatible stage entry points (host pointers, single frame) ---------- */
@@ -318,7 +320,7 @@ int vppx_occlusion_heuristic_full_dev(vppx_ctx *ctx, int B, int H, int W, const 
 /* Time `iters` back-to-back launches of the dominant kernel (8-path aggregation) on the
  * context's stream with hipEvents around the kernel only; returns average ms per launch
  * in *ms_out.  Operates on the workspace state left by the last vppx_rsgm_dev call. */
-/* hipGraph replay of vppx_vpp_rsgm_dev (also VPPX_GRAPH=1): with the mode on, the second call with identical
+/* hipGraph replay of vppx_vpp_rsgm_dev: with the mode on, the second call with identical
  * shapes, parameters, pointers and stream is stream-captured and later identical calls launch the instantiated
  * graph (one launch instead of ~40: matters for small batches).  Needs a non-default stream (vppx_set_stream);
  * where capture is not possible the call silently stays on the eager path.  vppx_graph_replays counts launches. */
@@ -353,12 +355,30 @@ int vppx_fused_pixels_per_wave(vppx_ctx *ctx);
  * to this device or shape.  A scheduling hint only: every batch size gives the same results.  (Runs a one-time device
  * probe on first use; not inside a graph capture.) */
 int vppx_batch_quantum(vppx_ctx *ctx, int H, int W, int dmax);
+/* Number of consecutive parts the last fused call (vppx_vpp_rsgm_dev / vppx_occ_vpp_rsgm_dev) ran as: a batch larger than
+ * one round of the lock-step kernel runs as parts of one round each (VPPX_CHUNK); 1 = the whole batch at once. */
+int vppx_last_call_parts(vppx_ctx *ctx);
 /* Per-stage hipEvent timing of the last vppx_vpp_rsgm_dev/vppx_rsgm_dev call when stage
  * timing is enabled: fills ms[0..n) and returns the number of stages; names via
  * vppx_stage_name(i). */
 int vppx_enable_stage_timing(vppx_ctx *ctx, int enable);
 int vppx_get_stage_ms(vppx_ctx *ctx, float *ms, int max_n);
 const char *vppx_stage_name(int i);
+
+/* ---- environment ------------------------------------------------------------------------------
+ * Every variable the shipped library reads, all of them ONCE, in vppx_create (nothing else calls getenv; `make EXP=1`
+ * measurement builds add VPPX_V3_IGNORE_LOST and VPPX_EXP_*, tools/ only):
+ *   VPPX_VERT           aggregation layout: -1 / unset = by shape, 0 = eight line-parallel paths, 3 = fused layout whenever the
+ *                       shape allows it, 1 = the round-1 band-marching kernel (vppx_uses_vert)
+ *   VPPX_CHUNK          parts of a fused call: unset = one round of the lock-step kernel each, 0 = whole batches, n = n frames
+ *   VPPX_SUBSTREAMS     1..4 child contexts that share a batch (default 1)
+ *   VPPX_V3_PPW         8 / 16: pixels per wave of the fused vertical kernel (default: by batch size)
+ *   VPPX_V3_TIMEOUT_MS  bound of one neighbour wait of the lock-step kernel (default 250)
+ *   VPPX_V3_SPIN_LIMIT  the same bound in polls (tests force the give-up path with 1; default unbounded)
+ *   VPPX_VARIANT        comma-separated tokens that select alternative kernels with identical results, each run by
+ *                       tests/test_gpu_variants.py: sum_general, sum_gl8, sum_trap0, sum_trap2 (fused sum / WTA kernel), gw4, gw8,
+ *                       gw16 (lanes per pixel of the line-parallel kernel), we_line (W / E on the line-parallel kernel),
+ *                       maxdist_lds, maxdist_global (one-wave maxDistance kernels) */
 
 #ifdef __cplusplus
 }

@@ -473,11 +473,14 @@ def test_full_size_odd_batches_take_the_fused_layout(B):
         assert torch.equal(outs[s], want), (B, s)
 
 
-@pytest.mark.parametrize("B,chunk", [(13, 5), (16, 8), (9, 4)])
-def test_parts_of_a_split_batch_equal_the_unsplit_call(B, chunk):
+# (B, chunk, parts): the remainder goes first, and below 8 frames it rides on the first full part: 13 = (3 + 5) + 5, 16 = 8 + 8,
+# 9 = (1 + 4) + 4, 27 = (3 + 8) + 8 + 8, 30 = (6 + 12) + 12 and 20 = 8 + 12 (uneven parts of 8 and more frames: fused layout)
+@pytest.mark.parametrize("B,chunk,parts", [(13, 5, 2), (16, 8, 2), (9, 4, 2), (27, 8, 3), (30, 12, 2), (20, 12, 2)])
+def test_parts_of_a_split_batch_equal_the_unsplit_call(B, chunk, parts):
     """A batch larger than one round of the lock-step kernel runs as consecutive parts (vppx_api.hip: vpp_rsgm_parts).  Forced
     here with VPPX_CHUNK on small frames: every output of the call -- disparities, mask, patterned pair -- must equal the
-    unsplit call's (frame f draws from srand(seed + f) whatever the split), with and without the cross-call overlap."""
+    unsplit call's (frame f draws from srand(seed + f) whatever the split), with and without the cross-call overlap; the
+    split must really have happened (vppx_last_call_parts), parts of growing size re-allocate the workspace while pipelined."""
     import torch
     H, W, D = 48, 112, 192
     split, whole = _engine(VPPX_CHUNK=chunk), _engine(VPPX_CHUNK=0)
@@ -492,6 +495,9 @@ def test_parts_of_a_split_batch_equal_the_unsplit_call(B, chunk):
             rv = torch.empty_like(lv)
             o = eng.vpp_rsgm(*args, g_occ="occlusion_heuristic", occ_out=occ, l_vpp=lv, r_vpp=rv, seed=5, rsgm_kw=dict(dmax=D, subpixel=1))
             eng.synchronize()
+            assert eng.last_call_parts() == (parts if name == "split" else 1), (name, eng.last_call_parts())
+            if B >= 16:
+                assert eng.uses_vert() == 3
             outs[(name, piped)] = (o.clone(), occ, lv, rv)
     ref = outs[("whole", False)]
     for key, got in outs.items():

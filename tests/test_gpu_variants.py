@@ -1,8 +1,10 @@
-"""GPU parity of the optional execution variants (environment knobs read at context creation):
+"""GPU parity of the optional execution variants (environment read at context creation, include/vppx.h "environment"):
 the aggregation layouts (VPPX_VERT: 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel; the default
-picks 3 from 8 frames per launch on), other lanes-per-pixel layouts (VPPX_GW) and
-sub-stream splitting (VPPX_SUBSTREAMS), the general sum / WTA decision code (VPPX_SUM_FAST=0) and the one-wave-per-chain
-maxDistance kernels (VPPX_MAXDIST_WAVE=0).  Each variant runs in a fresh process."""
+picks 3 from 6 frames per launch on), sub-stream splitting (VPPX_SUBSTREAMS) and every VPPX_VARIANT token: other
+lanes-per-pixel layouts of the line-parallel kernel (gw4 / gw8 / gw16), W / E on the line-parallel kernel (we_line), the
+general sum / WTA decision code (sum_general), 8 lanes per pixel in the sum kernel (sum_gl8), the D = 256 ring layouts
+(sum_trap0 / sum_trap2) and the one-wave-per-chain maxDistance kernels (maxdist_lds / maxdist_global).  Each variant runs in
+a fresh process."""
 import os
 import subprocess
 import sys
@@ -18,7 +20,7 @@ sys.path.insert(0, %r)
 import oracle, synth
 from vppstereo_amd.engine import Engine
 eng = Engine()
-for (B, H, W, D) in ((1, 24, 300, 256), (4, 50, 150, 192), (8, 40, 96, 64), (2, 70, 81, 128), (8, 21, 230, 192)):
+for (B, H, W, D) in ((1, 24, 300, 256), (4, 50, 150, 192), (8, 40, 96, 64), (2, 70, 81, 128), (8, 30, 200, 256), (8, 21, 230, 192)):
     b = synth.make_batch(B, H, W, D, 0.05, seed=B * H)
     dev = eng.device
     lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev); rv = torch.empty_like(lv)
@@ -31,13 +33,14 @@ for (B, H, W, D) in ((1, 24, 300, 256), (4, 50, 150, 192), (8, 40, 96, 64), (2, 
         lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f])
         assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), (B, f)
         assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D), out[f]), (B, H, W, D, f)
-print("VARIANT_OK", int(eng.uses_vert()))   # how the LAST shape (8 frames, D = 192) was aggregated
+print("VARIANT_OK", int(eng.uses_vert()))   # how the LAST shape (8 frames, D = 192) was aggregated (8 frames at D = 256: fused only with VPPX_VERT=3)
 """ % ROOT
 
 
-@pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_VERT="0"), dict(VPPX_VERT="3"), dict(VPPX_GW="16"), dict(VPPX_GW="4"),
-                                 dict(VPPX_GW="8"), dict(VPPX_SUBSTREAMS="2"), dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2"),
-                                 dict(VPPX_VERT="3", VPPX_SUBSTREAMS="2"), dict(VPPX_SUM_FAST="0"), dict()])
+@pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_VERT="0"), dict(VPPX_VERT="3"), dict(VPPX_VARIANT="gw16"), dict(VPPX_VARIANT="gw4"),
+                                 dict(VPPX_VARIANT="gw8"), dict(VPPX_SUBSTREAMS="2"), dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2"),
+                                 dict(VPPX_VERT="3", VPPX_SUBSTREAMS="2"), dict(VPPX_VARIANT="sum_general"), dict(VPPX_VARIANT="sum_gl8"),
+                                 dict(VPPX_VARIANT="we_line"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap0"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap2,we_line"), dict()])
 def test_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)
@@ -51,7 +54,7 @@ def test_variant_matches_oracle(env):
         assert "VARIANT_OK %d" % want in r.stdout, r.stdout[-300:]
 
 
-@pytest.mark.parametrize("env", [dict(VPPX_MAXDIST_WAVE="0"), dict(VPPX_MAXDIST_GLOBAL="1")])
+@pytest.mark.parametrize("env", [dict(VPPX_VARIANT="maxdist_lds"), dict(VPPX_VARIANT="maxdist_global")])
 def test_maxdist_one_wave_kernels_still_match_the_golden_cases(env):
     """The row-wavefront kernel is the default; the LDS-ring and in-place one-wave kernels stay as fall-backs
     (x-descending scans, frames too wide for the LDS ring) and must keep passing the same golden / anchor tests."""

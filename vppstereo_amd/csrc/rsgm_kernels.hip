@@ -1221,14 +1221,10 @@ int rsgm_launch_paths(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gra
     if (elem_bytes == 1 && p1 > 231) a.p1 = 231;
     // lanes per pixel x disparities per lane: few lanes per pixel amortise the per-step overhead
     // (min reduction, P2 lookup, addressing) over more disparities
-    static int gw_override = -1;
-    if (gw_override < 0) {
-        const char *e = getenv("VPPX_GW"); // experiment knob: lanes per pixel (other layouts per D range)
-        gw_override = e ? atoi(e) : 0;
-    }
+    const int gw_override = ctx->knobs.gw; // VPPX_VARIANT gw4 / gw8 / gw16: lanes per pixel (other layouts per D range)
     {
-        // W + E of the fused layout at D = 128 / 192 / 256: the register-window kernel (VPPX_WE12=0: the line kernel, for comparison)
-        static const int we12 = getenv("VPPX_WE12") ? atoi(getenv("VPPX_WE12")) : 1;
+        // W + E of the fused layout at D = 128 / 192 / 256: the register-window kernel (VPPX_VARIANT we_line: the line kernel)
+        const int we12 = !ctx->knobs.we_line;
         if (we12 && (D == 128 || D == 192 || D == 256) && a.dir_mask == 0x11 && !from_dsi && elem_bytes == 1 && Hp % 16 == 0 && Wp % 16 == 0 &&
             Wp >= 16 && gw_override <= 0)
             return launch_we12(ctx, B, Hp, Wp, D, gray, cl, cr, p2lut, p1, paths);
@@ -2861,6 +2857,256 @@ __global__ void __launch_bounds__(GL * T) sum_wta_lr_kernel(VolPtrs vols, float 
     if constexpr (FAST) flush();
 }
 
+// ---------------------------------------------------------------------------------------
+// Round 5: the fused sum / WTA kernel for D = 256 in the fused layout (sum_wta_trap_kernel).
+//
+// TRAPEZOID RING.  The right view of pixel xr reads S[xr + d][d]: of the tile k tiles ahead only the disparities
+// (k - 1) T < d < (k + 1) T.  The low disparities of a tile are dead long before the high ones are first needed, yet the
+// uniform ring of sum_wta_lr_kernel keeps all D rows of a tile for NR rounds: at D = 256 that is 9 tiles of 32 pixels =
+// 153 KB, a 512-thread block per CU (2 waves per SIMD, two barriers per round).  Here the disparity axis is cut into four
+// bands of D / 4 (the disparities of 4 lanes) and band q keeps only the NR - (q * D / 4) / T tiles somebody can still ask
+// for: with 64-pixel rounds 5 + 4 + 3 + 2 = 14 band slots of 8.4 KB (18 with a spare slot per band: one barrier per
+// round), so that D = 256 runs the 1024-thread, 64-pixel shape of D = 192.
+//
+// BANKS.  ds_read_u16 / ds_write_b16 see 32 banks of 4 bytes and serve a wave in two halves of 32 lanes = 2 pixels x 16
+// lanes (MI355X_MICROARCH.md, LDS).  In the uniform layout [d][T + 2] a lane's 16 rows put the lanes 528 dwords apart:
+// = 16 (mod 32), two banks for 16 lanes, an 8-way conflict on every ring write and 4-way on the diagonal gather (that,
+// not HBM, bounded the 32-pixel kernel: 3.1 TB/s).  A band slot here is lane-major with a lane pitch = 2 (mod 4) dwords
+// (the 16 lanes of a pixel then sit on 16 distinct even banks, its neighbour pixel in the same dwords or on the odd
+// banks), the slot pitch is a multiple of 32 dwords and the band bases continue the lane pitch: conflict-free writes
+// and gathers.  (The same count for D = 192: lane pitch 396 = 12 (mod 32): 2-way writes, which the 4-cycle operand
+// transfer of a store hides, and a conflict-free gather.)
+// ---------------------------------------------------------------------------------------
+template <int DPL, int T, int SP>
+struct TrapRing {
+    static constexpr int D = 16 * DPL, BW = 4 * DPL;    // four bands of four lanes
+    static constexpr int NR = (T + D - 2) / T + 1;      // tiles a right pixel can touch (x .. x + D - 1)
+    static constexpr int TW = T + 2;                    // row pitch in u16
+    static constexpr int LPD0 = DPL * TW / 2;           // dwords of a lane's DPL rows
+    static constexpr int LP = DPL * TW + 2 * ((2 - LPD0 % 4 + 4) % 4);  // lane pitch in u16: = 2 (mod 4) dwords
+    static constexpr int BS = 4 * LP + 2 * ((32 - (2 * LP) % 32) % 32); // band slot pitch in u16: a multiple of 32 dwords
+    static constexpr int nslots(int q) { return NR - (q * BW) / T + SP; }
+    static constexpr int base(int q)                    // u16 offset of band q's ring; = q * 4 lane pitches (mod 32 dwords)
+    {
+        int s = 0;
+        for (int i = 0; i < q; i++) s += nslots(i) * BS;
+        return s + 2 * ((q * 2 * LP) % 32);
+    }
+    static constexpr int total = base(3) + nslots(3) * BS;
+    static_assert(DPL * TW % 2 == 0 && (LP / 2) % 4 == 2 && (BS / 2) % 32 == 0, "bank layout");
+};
+
+template <int DPL, int T, bool SPARE>
+__global__ void __launch_bounds__(16 * T) sum_wta_trap_kernel(VolPtrs vols, float *__restrict__ disp_l, float *__restrict__ disp_r,
+                                                             int Hp, int Wp, u32 factor_uniq, int do_subpixel, int rows_per_block)
+{
+    constexpr int GL = 16, NV = 4, NP = DPL / 2, D = GL * DPL, NWD = NP / 2;
+    typedef TrapRing<DPL, T, SPARE ? 1 : 0> RG;
+    constexpr int NR = RG::NR, TW = RG::TW, BW = RG::BW, BS = RG::BS, LP = RG::LP;
+    extern __shared__ __attribute__((aligned(16))) u16 ring_alloc[]; // T guard elements, then the band rings
+    u16 *const ring = ring_alloc + T;
+    const int f = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int nrows = (Hp - r0 < rows_per_block) ? Hp - r0 : rows_per_block;
+    const size_t framepix = (size_t)f * Hp * Wp;
+    const int g = threadIdx.x / GL, l16 = threadIdx.x % GL;
+    const int dbase = DPL * l16;
+    const int q = l16 >> 2, l4 = l16 & 3;                // this lane's band and its place in it
+    int my_n = RG::nslots(0), my_base = RG::base(0);
+    if (q == 1) { my_n = RG::nslots(1); my_base = RG::base(1); }
+    if (q == 2) { my_n = RG::nslots(2); my_base = RG::base(2); }
+    if (q == 3) { my_n = RG::nslots(3); my_base = RG::base(3); }
+    my_base += l4 * LP;
+    // uniform ring cursors per band: slot of the tile the left view writes now, slot of the right view's own tile
+    int wcur[4] = {0, 0, 0, 0}, rcur[4] = {0, 0, 0, 0};
+    auto sel4 = [&](int b, u32 v0, u32 v1, u32 v2, u32 v3) -> u32 {
+        u32 v = v0;
+        v = b == 1 ? v1 : v;
+        v = b == 2 ? v2 : v;
+        v = b == 3 ? v3 : v;
+        return v;
+    };
+    // offset of disparity d inside a band slot (lane-major, then the lane's rows)
+    auto in_slot = [&](int d, int b) -> u32 {
+        const int r = d - b * BW;
+        return (u32)((r / DPL) * LP + (r % DPL) * TW);
+    };
+    u32 kl[5] = {0, 0, 0, 0, 0}, kr[5] = {0, 0, 0, 0, 0};
+    auto flush = [&]() {
+        if (kl[3]) {
+            const float dv = top2_final<DPL>(kl[0], kl[1], kl[2], (int)(kl[3] & 511u), D, factor_uniq, do_subpixel != 0, (kl[3] >> 9) & 1u);
+            disp_l[framepix + kl[4]] = dv;
+        }
+        if (kr[3]) {
+            const float dv = top2_final<DPL>(kr[0], kr[1], kr[2], (int)(kr[3] & 511u), D, factor_uniq, false, false);
+            disp_r[framepix + kr[4]] = dv;
+        }
+        kl[3] = 0;
+        kr[3] = 0;
+    };
+    const int ntiles = (Wp + T - 1) / T;
+    const int total = nrows * ntiles;
+    // stream cursors (uniform): fetch runs three rounds ahead of the left view, the right view NR-1 behind
+    int f_row = r0, f_k = 0;
+    int l_row = r0, l_k = 0;
+    int r_row = r0, r_k = 0;
+    u32 wa[NV][NWD], wb[NV][NWD], wc[NV][NWD];
+    auto fetch = [&](u32 (&w)[NV][NWD]) {
+        int x = T * f_k + g;
+        x = x < Wp ? x : Wp - 1;
+        const int frow = f_row < r0 + nrows ? f_row : r0 + nrows - 1;
+        const size_t rowoff = (framepix + (size_t)frow * Wp) * D; // uniform: scalar base + 32-bit lane offset
+        // cells with d > x + 1 have no reader: such a lane re-reads the pixel's first chunk (sum_wta_lr_kernel)
+        const u32 laneoff = (u32)x * D + (dbase <= x + 1 ? dbase : 0);
+#pragma unroll
+        for (int v = 0; v < NV; v++) load_words_nt<NWD>((const u32 *)((const u8 *)vols.v[v] + rowoff + laneoff), w[v]);
+        if (++f_k == ntiles) {
+            f_k = 0;
+            f_row++;
+        }
+    };
+    auto round = [&](int j, u32 (&w)[NV][NWD]) {
+        if (j < total) {
+            const int x = T * l_k + g;
+            u32 acc[NP];
+            // fused layout: W + E as packed bytes (cannot carry), widened, + the two three-path sums (<= 255 each) widened
+#pragma unroll
+            for (int i = 0; i < NP / 2; i++) {
+                const u32 ab = w[0][i] + w[1][i];
+                acc[2 * i] = __builtin_amdgcn_perm(ab, ab, 0x0c010c00u) + __builtin_amdgcn_perm(w[2][i], w[2][i], 0x0c010c00u) +
+                             __builtin_amdgcn_perm(w[3][i], w[3][i], 0x0c010c00u);
+                acc[2 * i + 1] = __builtin_amdgcn_perm(ab, ab, 0x0c030c02u) + __builtin_amdgcn_perm(w[2][i], w[2][i], 0x0c030c02u) +
+                                 __builtin_amdgcn_perm(w[3][i], w[3][i], 0x0c030c02u);
+            }
+            fetch(w); // this register set is free again
+            if (x < Wp) { // uniform per 16-lane group
+                const int wslot = (int)sel4(q, (u32)wcur[0], (u32)wcur[1], (u32)wcur[2], (u32)wcur[3]);
+                u16 *t = ring + my_base + wslot * BS + g;
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    t[(2 * i) * TW] = (u16)(acc[i] & 0xFFFFu);
+                    t[(2 * i + 1) * TW] = (u16)(acc[i] >> 16);
+                }
+                const int n = (x < D - 1 ? x : D - 1) + 1;
+                // the pixel's column was just written by this wave (LDS keeps a wave's accesses in order)
+                const u32 wb0 = RG::base(0) + wcur[0] * BS, wb1 = RG::base(1) + wcur[1] * BS, wb2 = RG::base(2) + wcur[2] * BS,
+                          wb3 = RG::base(3) + wcur[3] * BS;
+                const Top2 r = top2_reduce<DPL, GL>(acc, dbase, n, D, [&](int d) -> u32 {
+                    const int b = d / BW;
+                    return ring[sel4(b, wb0, wb1, wb2, wb3) + in_slot(d, b) + (u32)g];
+                });
+                if (l16 == (j & (GL - 1))) { // this lane keeps this round's pixel
+                    asm volatile("; keep (left view)");
+                    kl[0] = r.g1; kl[1] = r.g2; kl[2] = r.nbv;
+                    kl[3] = (u32)n | ((x >= 1 && x <= Wp - 2) ? 512u : 0u) | 1024u;
+                    kl[4] = (u32)(l_row * Wp + x);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) wcur[b] = (wcur[b] + 1 == RG::nslots(b)) ? 0 : wcur[b] + 1;
+            if (++l_k == ntiles) {
+                l_k = 0;
+                l_row++;
+            }
+        }
+        __syncthreads();
+        if (j >= NR - 1) {
+            const int xr = T * r_k + g;
+            if (xr < Wp) {
+                const int n = (Wp - 1 - xr < D - 1 ? Wp - 1 - xr : D - 1) + 1;
+                u32 sr[NP];
+                // S[xr+d][d] for the lane's DPL consecutive d: the column g + d crosses a tile border at most once, so two base
+                // addresses (this tile / the next, column wrapped) + a compile-time stride of one row + 1 serve all elements
+                const u32 a0 = (u32)(g + dbase);
+                int sA = (int)sel4(q, (u32)rcur[0], (u32)rcur[1], (u32)rcur[2], (u32)rcur[3]) + (int)(a0 / T);
+                sA = sA >= my_n ? sA - my_n : sA;
+                sA = sA >= my_n ? sA - my_n : sA;
+                int sB = sA + 1;
+                sB = sB >= my_n ? sB - my_n : sB;
+                const int lane_base = my_base + (int)(a0 % T);
+                const int RA = (int)__umul24((u32)sA, (u32)BS) + lane_base, RB = (int)__umul24((u32)sB, (u32)BS) + lane_base - T; // RB >= -T: guard elements
+                const int e_cross = T - (int)(a0 % T); // first element that lies in the next tile
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const u32 lo = ring[(2 * i < e_cross ? RA : RB) + (2 * i) * (TW + 1)];
+                    const u32 hi = ring[(2 * i + 1 < e_cross ? RA : RB) + (2 * i + 1) * (TW + 1)];
+                    sr[i] = lo | (hi << 16);
+                }
+                // an arbitrary disparity's band, packed: base | slots << 20 | the right view's cursor << 24
+                const u32 pb0 = (u32)RG::base(0) | ((u32)RG::nslots(0) << 20) | ((u32)rcur[0] << 24);
+                const u32 pb1 = (u32)RG::base(1) | ((u32)RG::nslots(1) << 20) | ((u32)rcur[1] << 24);
+                const u32 pb2 = (u32)RG::base(2) | ((u32)RG::nslots(2) << 20) | ((u32)rcur[2] << 24);
+                const u32 pb3 = (u32)RG::base(3) | ((u32)RG::nslots(3) << 20) | ((u32)rcur[3] << 24);
+                const Top2 r = top2_reduce<DPL, GL>(sr, dbase, n, D, [&](int d) -> u32 {
+                    const int b = d / BW;
+                    const u32 pk = sel4(b, pb0, pb1, pb2, pb3);
+                    const int nb_ = (int)((pk >> 20) & 15u);
+                    const u32 a = (u32)(g + d);
+                    int sl = (int)(pk >> 24) + (int)(a / T);
+                    sl = sl >= nb_ ? sl - nb_ : sl;
+                    sl = sl >= nb_ ? sl - nb_ : sl;
+                    return ring[(pk & 0xFFFFFu) + __umul24((u32)sl, (u32)BS) + in_slot(d, b) + (a % T)];
+                });
+                if (l16 == (j & (GL - 1))) {
+                    asm volatile("; keep (right view)");
+                    kr[0] = r.g1; kr[1] = r.g2; kr[2] = r.nbv;
+                    kr[3] = (u32)n | 1024u;
+                    kr[4] = (u32)(r_row * Wp + xr);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) rcur[b] = (rcur[b] + 1 == RG::nslots(b)) ? 0 : rcur[b] + 1;
+            if (++r_k == ntiles) {
+                r_k = 0;
+                r_row++;
+            }
+        }
+        if ((j & (GL - 1)) == GL - 1) flush(); // every lane of the wave holds a pixel of its own now
+        if (!SPARE) __syncthreads();
+    };
+    fetch(wa);
+    fetch(wb);
+    fetch(wc);
+    for (int j = 0; j < total + NR - 1; j += 3) {
+        round(j, wa);
+        if (j + 1 < total + NR - 1) round(j + 1, wb);
+        if (j + 2 < total + NR - 1) round(j + 2, wc);
+    }
+    flush();
+}
+
+template <int DPL, int T, bool SPARE>
+static int launch_trap(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
+{
+    typedef TrapRing<DPL, T, SPARE ? 1 : 0> RG;
+    const size_t lds = ((size_t)RG::total + T) * sizeof(u16);
+    static bool attr_set[VPPX_MAX_DEVICES] = {}; // function attributes are per device
+    static int ncu_of[VPPX_MAX_DEVICES] = {};
+    const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
+    if (!attr_set[dv]) {
+        VPPX_HIP(hipFuncSetAttribute((const void *)sum_wta_trap_kernel<DPL, T, SPARE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipDeviceProp_t prop;
+        VPPX_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        ncu_of[dv] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        attr_set[dv] = true;
+    }
+    // one block per CU is resident (LDS): the rows-per-block split with the shortest makespan (launch_lr_t2)
+    const int ncu = ncu_of[dv], ntiles = (Wp + T - 1) / T;
+    int chunks = 1;
+    long best = -1;
+    for (int c = 1; c <= Hp && c <= 256; c++) {
+        const long rows = (Hp + c - 1) / c;
+        const long nb = (long)((Hp + rows - 1) / rows) * B;
+        const long cost = ((nb + ncu - 1) / ncu) * (rows * ntiles + RG::NR + 2);
+        if (best < 0 || cost < best) { best = cost; chunks = c; }
+    }
+    const int rpb = (Hp + chunks - 1) / chunks;
+    chunks = (Hp + rpb - 1) / rpb;
+    sum_wta_trap_kernel<DPL, T, SPARE><<<dim3(chunks, B), 16 * T, lds, ctx->stream>>>(vp, disp_l, disp_r, Hp, Wp, fu, sub, rpb);
+    VPPX_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int DPL, typename IT, int NV, int T, bool SPARE, bool SW4, bool FAST = false, int GL = 16, bool FULLW = false>
 static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, float *disp_l, float *disp_r, u32 fu, int sub)
 {
@@ -2880,7 +3126,7 @@ static int launch_lr_t2(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp,
     }
     // one block per CU is resident (LDS): pick the rows-per-block split with the shortest makespan,
     // (waves of blocks over the CUs) x (rounds per block incl. its fill/drain rounds)
-    static int forced = getenv("VPPX_SUM_BLOCKS") ? atoi(getenv("VPPX_SUM_BLOCKS")) : 0;
+    const int forced = ctx->knobs.sum_blocks;
     static int ncu_of[VPPX_MAX_DEVICES] = {};
     if (!ncu_of[dv]) {
         hipDeviceProp_t prop;
@@ -2914,11 +3160,11 @@ static int launch_lr_t(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
                        bool sw4)
 {
     if constexpr (sizeof(IT) == 1) {
-        static const int fast = getenv("VPPX_SUM_FAST") ? atoi(getenv("VPPX_SUM_FAST")) : 1;
-        // VPPX_SUM_GL=8 (experiment): 8 lanes per pixel with twice the disparities per lane for D = 128 / 192.  A fifth fewer
+        const int fast = !ctx->knobs.sum_general;
+        // VPPX_VARIANT sum_gl8: 8 lanes per pixel with twice the disparities per lane for D = 128 / 192.  A fifth fewer
         // instructions, but one 512-thread block per CU (the LDS ring) is 2 waves per SIMD between two block-wide barriers
         // per round: 2.89 ms per B=32 launch against 2.44 with 16 lanes per pixel (4 waves per SIMD).  Bit-exact all the same.
-        static const int gl = getenv("VPPX_SUM_GL") ? atoi(getenv("VPPX_SUM_GL")) : 16;
+        const int gl = ctx->knobs.sum_gl8 ? 8 : 16;
         if constexpr (DPL == 8 || DPL == 12) {
             if (sw4 && fast && gl == 8) return launch_lr_t2<2 * DPL, IT, NV, T, SPARE, true, true, 8>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
         }
@@ -2932,6 +3178,15 @@ template <typename IT, int NV>
 static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, int D, float *disp_l, float *disp_r, u32 fu,
                        int sub, bool sw4)
 {
+    // D = 256 in the fused layout: the trapezoid ring (64-pixel rounds, 1024 threads; VPPX_VARIANT sum_trap2: with a spare slot per
+    // band, one barrier per round; sum_trap0: the 32-pixel rounds of the uniform ring)
+    if constexpr (sizeof(IT) == 1 && NV == 4) {
+        const int trap = ctx->knobs.sum_trap, fast = !ctx->knobs.sum_general;
+        if (D == 256 && trap && fast && sw4) {
+            if (trap == 2) return launch_trap<16, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+            return launch_trap<16, 64, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+        }
+    }
     // LDS ring: (tiles) x D x (T+2) u16 must fit 160 KiB
     if (D == 64) return launch_lr_t<4, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub, sw4);
     if (D == 128) return launch_lr_t<8, IT, NV, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub, sw4);
@@ -2941,8 +3196,9 @@ static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
 
 // LDS of one block of the fused sum / WTA kernel (its tile ring; launch_lr_d / launch_lr_t2): what a kernel that runs next to it
 // cannot have
-size_t rsgm_sum_lds_bytes(int D)
+size_t rsgm_sum_lds_bytes(int D, int nvol)
 {
+    if (D == 256 && nvol == 4) return ((size_t)TrapRing<16, 64, 0>::total + 64) * sizeof(u16); // trapezoid ring (launch_lr_d)
     const int T = D == 256 ? 32 : 64;
     const int NT = (T + D - 2) / T + 1 + (D == 256 ? 0 : 1);
     return ((size_t)NT * D * (T + 2) + T) * sizeof(u16);

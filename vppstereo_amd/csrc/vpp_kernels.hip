@@ -1849,8 +1849,8 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
         const int rad = k.n + m.n_agg_y;
         const size_t lds = (size_t)2 * (2 * rad + 1) * g.W;
         const size_t lds_wave = (size_t)2 * MD_RING * g.W;
-        static const int md_wave = getenv("VPPX_MAXDIST_WAVE") ? atoi(getenv("VPPX_MAXDIST_WAVE")) : 1;
-        if (md_wave && k.direction && 2 * rad + 2 <= MD_RING && lds_wave <= 132 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
+        const int md = ctx->knobs.maxdist; // VPPX_VARIANT maxdist_lds (1) / maxdist_global (2): the one-wave-per-chain kernels
+        if (md == 0 && k.direction && 2 * rad + 2 <= MD_RING && lds_wave <= 132 * 1024) {
             // row wavefront: MD_NW waves per chain
             static bool attr_set[VPPX_MAX_DEVICES] = {};
             if (!attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)]) {
@@ -1858,7 +1858,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
                 attr_set[ctx->device & (VPPX_MAX_DEVICES - 1)] = true;
             }
             maxdist_wave_kernel<<<dim3(g.B * g.C), 64 * MD_NW, lds_wave, ctx->stream>>>(m, rad);
-        } else if (lds <= 60 * 1024 && !getenv("VPPX_MAXDIST_GLOBAL")) {
+        } else if (lds <= 60 * 1024 && md != 2) {
             maxdist_lds_kernel<<<dim3(g.B * g.C), 64, lds, ctx->stream>>>(m, rad);
         } else {
             maxdist_kernel<<<dim3(g.B * g.C), 64, 0, ctx->stream>>>(m);

@@ -168,10 +168,28 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
     {
         const char *e = getenv("VPPX_VERT");
         ctx->use_vert = e ? atoi(e) : -1;
-        e = getenv("VPPX_GRAPH");
-        if (e && atoi(e) > 0) ctx->graph_mode = true;
-        e = getenv("VPPX_PIPE_MID"); // 1: the next front stage starts behind the vertical kernel, next to W/E (measured: 9.16 -> 9.6 ms per step, W/E 0.99 -> 1.15 ms per 16 frames)
-        if (e) ctx->pipe_mid = atoi(e) != 0;
+        e = getenv("VPPX_CHUNK");
+        if (e) ctx->knobs.chunk = atoi(e);
+        e = getenv("VPPX_VARIANT"); // comma-separated tokens: alternative kernels with identical results (vppx_internal.h, Knobs)
+        if (e) {
+            std::string v(e);
+            auto has = [&](const char *tok) { return ("," + v + ",").find(std::string(",") + tok + ",") != std::string::npos; };
+            if (has("sum_general")) ctx->knobs.sum_general = 1;
+            if (has("gw4")) ctx->knobs.gw = 4;
+            if (has("gw8")) ctx->knobs.gw = 8;
+            if (has("gw16")) ctx->knobs.gw = 16;
+            if (has("maxdist_lds")) ctx->knobs.maxdist = 1;
+            if (has("maxdist_global")) ctx->knobs.maxdist = 2;
+            if (has("we_line")) ctx->knobs.we_line = 1;
+            if (has("sum_gl8")) ctx->knobs.sum_gl8 = 1;
+            if (has("sum_trap0")) ctx->knobs.sum_trap = 0;
+            if (has("sum_trap2")) ctx->knobs.sum_trap = 2;
+#ifdef VPPX_EXPERIMENT
+            if (has("pipe_mid")) ctx->pipe_mid = true; // the next front stage starts behind the vertical kernel, next to W/E (measured: 9.16 -> 9.6 ms per step)
+            const size_t sb = v.find("sum_blocks=");
+            if (sb != std::string::npos) ctx->knobs.sum_blocks = atoi(v.c_str() + sb + 11);
+#endif
+        }
         e = getenv("VPPX_SUBSTREAMS");
         if (e) ctx->nsub = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
         // bounds of one neighbour wait in the fused aggregation kernel: milliseconds of wall clock (the bound that counts)
@@ -1242,7 +1260,7 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
         if (r_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {r_user, r_vpp, nb, false};
     }
     {   // what the front-stage kernels may use of a CU's LDS: next to the previous part's sum / WTA kernel when pipelined
-        const size_t sum_lds = rsgm_sum_lds_bytes(rp->dmax), cu_lds = 160 * 1024;
+        const size_t sum_lds = rsgm_sum_lds_bytes(rp->dmax, B >= VPPX_FUSED_MIN_FRAMES ? 4 : 8), cu_lds = 160 * 1024; // (the previous part has this part's shape)
         const size_t left_over = cu_lds > sum_lds + 512 ? cu_lds - sum_lds - 512 : 2048;
         ctx->front_lds_budget = (piped && left_over < 64 * 1024) ? left_over : 64 * 1024;
     }
@@ -1324,7 +1342,7 @@ static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
                           uint8_t *conf_out, uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out)
 {
     int rc;
-    static const int chunk_env = getenv("VPPX_CHUNK") ? atoi(getenv("VPPX_CHUNK")) : -1;
+    const int chunk_env = ctx->knobs.chunk;
     int q = 0;
     if (chunk_env > 0) {
         q = chunk_env;
@@ -1344,7 +1362,9 @@ static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
             if (fused) q = fpr;
         }
     }
+    ctx->last_parts = 1;
     if (q <= 0 || q >= B) return vpp_rsgm_one(ctx, op, vp, rp, B, H, W, C, left, right, g, g_occ, conf_out, l_vpp, r_vpp, disp_out);
+    ctx->last_parts = 0;
     const size_t fpx = (size_t)H * W;
     void *const inputs_ev = ctx->inputs_ev; // one-shot per CALL: every part's front stage may start on it
     int lo = 0;
@@ -1363,10 +1383,13 @@ static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
                           disp_out + (size_t)lo * fpx);
         ctx->stage_append = false;
         if (rc) return rc;
+        ctx->last_parts++;
         lo += nb;
     }
     return 0;
 }
+
+extern "C" int vppx_last_call_parts(vppx_ctx *ctx) { return ctx ? ctx->last_parts : 0; }
 
 static int vpp_rsgm_entry(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
                           int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,

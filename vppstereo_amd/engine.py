@@ -336,6 +336,10 @@ class Engine:
         3 = W/E line-parallel + the fused three-path vertical kernel (default from 8 frames per launch on)."""
         return int(self.lib.vppx_uses_vert(self.ctx.handle))
 
+    def last_call_parts(self):
+        """Parts the last fused call ran as (a batch larger than one round of the lock-step kernel is split; 1 = unsplit)."""
+        return int(self.lib.vppx_last_call_parts(self.ctx.handle))
+
     def fused_pixels_per_wave(self):
         """16 / 8: which fused vertical kernel the last call used (sgm_vert4_kernel / sgm_vert3_kernel); 0: none."""
         return int(self.lib.vppx_fused_pixels_per_wave(self.ctx.handle))
