@@ -3,7 +3,7 @@ the aggregation layouts (VPPX_VERT: 0 eight line-parallel paths, 1 band marching
 picks 3 from 6 frames per launch on), sub-stream splitting (VPPX_SUBSTREAMS) and every VPPX_VARIANT token: other
 lanes-per-pixel layouts of the line-parallel kernel (gw4 / gw8 / gw16), W / E on the line-parallel kernel (we_line), the
 general sum / WTA decision code (sum_general), 8 lanes per pixel in the sum kernel (sum_gl8), the D = 256 ring layouts
-(sum_trap0 / sum_trap2) and the one-wave-per-chain maxDistance kernels (maxdist_lds / maxdist_global).  Each variant runs in
+(sum_trap0 / sum_trap1) and the one-wave-per-chain maxDistance kernels (maxdist_lds / maxdist_global).  Each variant runs in
 a fresh process."""
 import os
 import subprocess
@@ -40,7 +40,7 @@ print("VARIANT_OK", int(eng.uses_vert()))   # how the LAST shape (8 frames, D = 
 @pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_VERT="0"), dict(VPPX_VERT="3"), dict(VPPX_VARIANT="gw16"), dict(VPPX_VARIANT="gw4"),
                                  dict(VPPX_VARIANT="gw8"), dict(VPPX_SUBSTREAMS="2"), dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2"),
                                  dict(VPPX_VERT="3", VPPX_SUBSTREAMS="2"), dict(VPPX_VARIANT="sum_general"), dict(VPPX_VARIANT="sum_gl8"),
-                                 dict(VPPX_VARIANT="we_line"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap0"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap2,we_line"), dict()])
+                                 dict(VPPX_VARIANT="we_line"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap0"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap1,we_line"), dict()])
 def test_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)

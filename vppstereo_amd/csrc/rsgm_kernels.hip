@@ -3178,13 +3178,14 @@ template <typename IT, int NV>
 static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, int D, float *disp_l, float *disp_r, u32 fu,
                        int sub, bool sw4)
 {
-    // D = 256 in the fused layout: the trapezoid ring (64-pixel rounds, 1024 threads; VPPX_VARIANT sum_trap2: with a spare slot per
-    // band, one barrier per round; sum_trap0: the 32-pixel rounds of the uniform ring)
+    // D = 256 in the fused layout: the trapezoid ring (64-pixel rounds, 1024 threads) with a spare slot per band, i.e. one barrier
+    // per round (155 KB of LDS; measured at 8 x 1536x2048: 5.1 ms against 5.5 without the spare slots -- VPPX_VARIANT sum_trap1,
+    // 120 KB, two barriers -- and 8.2 on the uniform ring with 32-pixel rounds, sum_trap0)
     if constexpr (sizeof(IT) == 1 && NV == 4) {
         const int trap = ctx->knobs.sum_trap, fast = !ctx->knobs.sum_general;
         if (D == 256 && trap && fast && sw4) {
-            if (trap == 2) return launch_trap<16, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
-            return launch_trap<16, 64, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+            if (trap == 1) return launch_trap<16, 64, false>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
+            return launch_trap<16, 64, true>(ctx, vp, B, Hp, Wp, disp_l, disp_r, fu, sub);
         }
     }
     // LDS ring: (tiles) x D x (T+2) u16 must fit 160 KiB
@@ -3196,9 +3197,10 @@ static int launch_lr_d(vppx_ctx *ctx, const VolPtrs &vp, int B, int Hp, int Wp, 
 
 // LDS of one block of the fused sum / WTA kernel (its tile ring; launch_lr_d / launch_lr_t2): what a kernel that runs next to it
 // cannot have
-size_t rsgm_sum_lds_bytes(int D, int nvol)
+size_t rsgm_sum_lds_bytes(const vppx_ctx *ctx, int D, int nvol)
 {
-    if (D == 256 && nvol == 4) return ((size_t)TrapRing<16, 64, 0>::total + 64) * sizeof(u16); // trapezoid ring (launch_lr_d)
+    if (D == 256 && nvol == 4 && ctx->knobs.sum_trap && !ctx->knobs.sum_general) // trapezoid ring (launch_lr_d)
+        return ((size_t)(ctx->knobs.sum_trap == 1 ? TrapRing<16, 64, 0>::total : TrapRing<16, 64, 1>::total) + 64) * sizeof(u16);
     const int T = D == 256 ? 32 : 64;
     const int NT = (T + D - 2) / T + 1 + (D == 256 ? 0 : 1);
     return ((size_t)NT * D * (T + 2) + T) * sizeof(u16);

@@ -183,7 +183,7 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
             if (has("we_line")) ctx->knobs.we_line = 1;
             if (has("sum_gl8")) ctx->knobs.sum_gl8 = 1;
             if (has("sum_trap0")) ctx->knobs.sum_trap = 0;
-            if (has("sum_trap2")) ctx->knobs.sum_trap = 2;
+            if (has("sum_trap1")) ctx->knobs.sum_trap = 1;
 #ifdef VPPX_EXPERIMENT
             if (has("pipe_mid")) ctx->pipe_mid = true; // the next front stage starts behind the vertical kernel, next to W/E (measured: 9.16 -> 9.6 ms per step)
             const size_t sb = v.find("sum_blocks=");
@@ -1260,7 +1260,7 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
         if (r_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {r_user, r_vpp, nb, false};
     }
     {   // what the front-stage kernels may use of a CU's LDS: next to the previous part's sum / WTA kernel when pipelined
-        const size_t sum_lds = rsgm_sum_lds_bytes(rp->dmax, B >= VPPX_FUSED_MIN_FRAMES ? 4 : 8), cu_lds = 160 * 1024; // (the previous part has this part's shape)
+        const size_t sum_lds = rsgm_sum_lds_bytes(ctx, rp->dmax, B >= VPPX_FUSED_MIN_FRAMES ? 4 : 8), cu_lds = 160 * 1024; // (the previous part has this part's shape)
         const size_t left_over = cu_lds > sum_lds + 512 ? cu_lds - sum_lds - 512 : 2048;
         ctx->front_lds_budget = (piped && left_over < 64 * 1024) ? left_over : 64 * 1024;
     }
@@ -1853,6 +1853,64 @@ static int time_aggregation(vppx_ctx *ctx, int iters, int which, float *ms_out)
     (void)hipEventDestroy(e1);
     return 0;
 }
+
+#ifdef VPPX_EXPERIMENT
+// Experiment (tools/overlap_probe.py): the sum / WTA kernel of the last fused call and a W/E launch of the same size started
+// TOGETHER on two streams, `iters` times; ms[0] = wall time per pair, ms[1] / ms[2] = each kernel's own duration inside the pair.
+// mode 1 = sum only, 2 = W/E only, 3 = both.  The W/E launch writes a scratch volume (the sum keeps reading valid data).
+// lds_pad > 0: the W/E blocks ask for that much extra dynamic LDS (caps how many of them fit next to a sum block).
+extern "C" int vppx_exp_overlap(vppx_ctx *ctx, int mode, int iters, float *ms)
+{
+    int rc;
+    VPPX_ENTER(ctx);
+    if (!ctx->have_last || ctx->last_vert != 3 || iters <= 0 || !ms) { vppx_set_error("vppx_exp_overlap: call the fused path first"); return VPPX_E_INVALID_ARG; }
+    const VppxRsgmParams &p = ctx->last_rp;
+    u16 lut_h[256];
+    int maxp2;
+    p2_lut_host(p, lut_h, &maxp2);
+    const int B = ctx->last_B, Hp = ctx->last_Hp, Wp = ctx->last_Wp, D = ctx->last_D;
+    const size_t ncell = (size_t)B * Hp * Wp * D;
+    void *scratch;
+    if ((rc = ws_reserve(ctx, WS_DSI, ncell * 2, &scratch))) return rc;
+    const void *vols[8] = {ctx->ws[WS_PATHS].p, (const u8 *)ctx->ws[WS_PATHS].p + ncell, ctx->ws[WS_SV].p, (const u8 *)ctx->ws[WS_SV].p + ncell};
+    hipStream_t sa = ctx->stream, sb = ctx->stream2;
+    hipEvent_t e0, e1, a0, a1, b0, b1, ej;
+    for (hipEvent_t *e : {&e0, &e1, &a0, &a1, &b0, &b1, &ej}) VPPX_HIP(hipEventCreate(e));
+    VPPX_HIP(hipStreamSynchronize(sa));
+    VPPX_HIP(hipStreamSynchronize(sb));
+    float tot[3] = {0, 0, 0};
+    for (int i = 0; i < iters; i++) {
+        VPPX_HIP(hipEventRecord(e0, sa));
+        VPPX_HIP(hipStreamWaitEvent(sb, e0, 0));
+        if (mode & 2) {
+            hipStream_t keep = ctx->stream;
+            ctx->stream = sb;
+            VPPX_HIP(hipEventRecord(b0, sb));
+            rc = rsgm_launch_paths(ctx, B, Hp, Wp, D, ctx->last_gl, ctx->last_cl, ctx->last_cr, nullptr, (const u16 *)ctx->ws[WS_P2LUT].p, p.p1, scratch, 1, 0x11);
+            VPPX_HIP(hipEventRecord(b1, sb));
+            ctx->stream = keep;
+            if (rc) return rc;
+        }
+        if (mode & 1) {
+            VPPX_HIP(hipEventRecord(a0, sa));
+            rc = rsgm_launch_sum_wta_lr(ctx, B, Hp, Wp, D, vols, 4, 1, (float *)ctx->ws[WS_DISP_L0].p, (float *)ctx->ws[WS_DISP_R0].p, uniq_factor(p.uniqueness), 1, 24 + maxp2);
+            VPPX_HIP(hipEventRecord(a1, sa));
+            if (rc) return rc;
+        }
+        VPPX_HIP(hipEventRecord(ej, sb));
+        VPPX_HIP(hipStreamWaitEvent(sa, ej, 0));
+        VPPX_HIP(hipEventRecord(e1, sa));
+        VPPX_HIP(hipEventSynchronize(e1));
+        float t = 0.f;
+        VPPX_HIP(hipEventElapsedTime(&t, e0, e1)); tot[0] += t;
+        if (mode & 1) { VPPX_HIP(hipEventElapsedTime(&t, a0, a1)); tot[1] += t; }
+        if (mode & 2) { VPPX_HIP(hipEventElapsedTime(&t, b0, b1)); tot[2] += t; }
+    }
+    for (int k = 0; k < 3; k++) ms[k] = tot[k] / (float)iters;
+    for (hipEvent_t e : {e0, e1, a0, a1, b0, b1, ej}) (void)hipEventDestroy(e);
+    return 0;
+}
+#endif
 
 // whole aggregation stage (all launches of the 8 paths) per batch
 extern "C" int vppx_time_aggregate(vppx_ctx *ctx, int iters, float *ms_out) { return time_aggregation(ctx, iters, 0, ms_out); }

@@ -130,7 +130,7 @@ struct vppx_ctx {
         int maxdist = 0;      // "maxdist_lds" (1): one wave per chain, rows in LDS; "maxdist_global" (2): in place in global memory
         int we_line = 0;      // "we_line": W / E of the fused layout on the line-parallel kernel instead of sgm_we12_kernel
         int sum_gl8 = 0;      // "sum_gl8": 8 lanes per pixel in the fused sum / WTA kernel (D = 128 / 192)
-        int sum_trap = 1;     // "sum_trap0": D = 256 on the uniform ring (32-pixel rounds); "sum_trap2": trapezoid ring with spare slots
+        int sum_trap = 2;     // D = 256, fused layout: trapezoid ring with spare slots; "sum_trap1": without them; "sum_trap0": uniform ring, 32-pixel rounds
         int sum_blocks = 0;   // (EXP=1 builds) "sum_blocks=N": forced number of blocks of the sum / WTA kernel
     } knobs;
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
@@ -311,7 +311,7 @@ int rsgm_launch_wta_right_t(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u
 int rsgm_paths_elem_bytes(int D, int maxp2);
 // fused sum + left/right WTA; returns 1 (not an error) when the shape is not covered
 // max_path_value: upper bound of one path value (Cmax + P2max); 0 = unknown
-size_t rsgm_sum_lds_bytes(int D, int nvol);
+size_t rsgm_sum_lds_bytes(const vppx_ctx *ctx, int D, int nvol);
 int rsgm_launch_sum_wta_lr(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const void *const *vols, int nvol, int elem_bytes,
                            float *disp_l, float *disp_r, u32 factor_uniq, int do_subpixel, int max_path_value);
 int rsgm_launch_wta_left(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u16 *S, float *disp, u32 factor_uniq);
