@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 AGG_BYTES_PER_CELL = 10.0        # aggregation share of the 16 B/cell algorithmic bytes
 PATH_BYTES_PER_CELL = 16.0       # whole path, + 50 B/pixel
 PATH_BYTES_PER_PIXEL = 50.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
 # average issue cost of one VALU wave-instruction of the FUSED VERTICAL kernel's row loop (and of no other kernel: it is only
 # applied to the dominant kernel's own instruction count): its mix of full-rate (~2.5 cycles) and half-rate (~4 cycles:
@@ -76,6 +76,9 @@ def parse(argv=None):
                          "instead of the textured scenes; GPU timing only")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the bounded runs of the other BASELINE configurations (cfg 3 KITTI B=32, cfg 5 1536x2048x256 B=8)")
+    ap.add_argument("--sustained-steps", type=int, default=500,
+                    help="further steps timed AFTER the K timed ones (power steady state of the chip; 0 = skip); reported as "
+                         "ms_per_step_sustained, never as value")
     ap.add_argument("--spawn-check", action="store_true",
                     help="rank processes only form the process group (gloo, CPU) and report the frame plan: launcher self-test")
     return ap.parse_args(argv)
@@ -212,7 +215,10 @@ def cpu_baseline(n_frames, gpu_out=None):
                 sample=f"{n_frames} full {H}x{W}x{D} frames (occlusion heuristic + VPP rnd + rSGM), oracle/liboracle.so "
                        f"gcc {_oracle_flags().split(' -fPIC')[0]}, 1 thread, {t_tot / n_frames:.2f} s/frame, "
                        f"host has {os.cpu_count()} cpus; the port's rSGM is scalar C, about an order of magnitude slower than the "
-                       "SSE rSGM of the literature (SURVEY section 6): the GPU/CPU ratio is not a kernel-quality figure")
+                       "SSE rSGM of the literature (SURVEY section 6): the GPU/CPU ratio is not a kernel-quality figure.  Calibration "
+                       "against the real reference (profiles/r05_cpu_calibration.json, tools/calibrate_cpu.py): the VPP half of the port "
+                       "takes 0.49x the time of the reference's Cython scan (5.4 vs 10.9 ms per frame, bit-identical); the rSGM half "
+                       "(> 99 % of the time) cannot be calibrated, pyrSGM is not in the reference's tree")
     return base, epe
 
 
@@ -252,51 +258,6 @@ def kernel_source_sha():
             with open(os.path.join(d, name), "rb") as f:
                 h.update(f.read())
     return h.hexdigest()[:16]
-
-
-class SclkSampler:
-    """Shader clock while the timed region runs, read from the driver's sysfs table (pp_dpm_sclk: the active level is
-    starred) by a background thread; None when the box does not expose it."""
-
-    def __init__(self, dev_index=0, period=0.02):
-        import glob
-        import threading
-        self.samples, self._stop, self._path = [], threading.Event(), None
-        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if cands:
-            self._path = cands[min(dev_index, len(cands) - 1)]
-        self._period = period
-        self._thr = threading.Thread(target=self._run, daemon=True)
-
-    def _read(self):
-        try:
-            with open(self._path) as f:
-                for line in f:
-                    if "*" in line:
-                        return float(line.split(":")[1].replace("Mhz", "").replace("MHz", "").replace("*", "").strip())
-        except Exception:
-            return None
-        return None
-
-    def _run(self):
-        while not self._stop.is_set():
-            v = self._read()
-            if v:
-                self.samples.append(v)
-            self._stop.wait(self._period)
-
-    def __enter__(self):
-        if self._path:
-            self._thr.start()
-        return self
-
-    def __exit__(self, *a):
-        self._stop.set()
-        if self._path:
-            self._thr.join(timeout=1.0)
-
-    def mhz(self):
-        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
 
 
 def load_pmc():
@@ -509,8 +470,7 @@ def run_rank(args):
     drain()
     eng.agg_kernel_ms(0)  # reset: the hipEvent pairs around the aggregation launches of the timed steps only
     eng.we_kernel_ms(0)
-    with SclkSampler(dev_index) as sclk:
-        dt_local = timed(args.steps, step)
+    dt_local = timed(args.steps, step)
     eng.status()   # raises if a fused aggregation launch of the timed region lost its lock step (its disparities would be void)
     dt = dt_local
     rank_ms = [dt_local / args.steps * 1e3]
@@ -523,6 +483,16 @@ def run_rank(args):
         dt = max(float(x.item()) for x in allt)
     if args.graph:
         assert eng.graph_replays() > 0, "--graph was given but no call was served by a graph replay"
+    # power steady state: the timed region is a fraction of a second on a chip that clocks by its power budget; the same loop
+    # for `--sustained-steps` further steps (every rank: `timed` has barriers), reported next to the K-step figure
+    ms_sustained = None
+    if args.sustained_steps > 0:
+        ms_sustained = timed(args.sustained_steps, step) / args.sustained_steps * 1e3
+        if world > 1:
+            t = torch.tensor([ms_sustained], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_sustained = float(t.item())
+        eng.status()
     # the same steps with the cross-step overlap off (every rank: `timed` has barriers)
     ms_unpipelined = None
     if not (args.no_pipeline or args.graph):
@@ -554,8 +524,8 @@ def run_rank(args):
         if agg_n == 0 or agg_ms <= 0:   # graph replays carry no event pairs
             agg_ms = agg_ms_b2b
         agg_frames = eng.time_aggregate_frames()  # frames per launch (the batch is split over sub-streams)
-        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
-        cells_launch = agg_frames * Hp * Wp * D
+        cells_launch = agg_frames * H * W * D     # SURVEY 8d counts unpadded cells
+        launches_per_step = max(1, -(-B // agg_frames)) if agg_frames else 1
         # SURVEY 8d prices the 8-path aggregation at 10 B/cell; the fused vertical kernel carries 6 of the 8 paths
         agg_bytes = AGG_BYTES_PER_CELL * (6.0 / 8.0 if fused else 1.0)
         wide = fused and eng.fused_pixels_per_wave() == 16
@@ -593,18 +563,15 @@ def run_rank(args):
         pmc_all = load_pmc()
         pmc_ok = bool(pmc_all) and pmc_all.get("batch") == agg_frames and (pmc_all.get("H"), pmc_all.get("W"), pmc_all.get("D")) == (H, W, D)
         step_traffic = round(pmc_all["hbm_GB_per_step"], 3) if pmc_ok and pmc_all.get("hbm_GB_per_step") else None
-        sclk_mhz = sclk.mhz()
         valu = None
         if pmc and pmc.get("SQ_INSTS_VALU"):
             # shader clock of THIS kernel under load: GRBM_GUI_ACTIVE (shader-clock cycles per XCD, summed over the 8 XCDs)
-            # / 8 / the kernel's duration, both from the SQ pass of the committed profile; the sysfs DPM table sampled
-            # during the timed region only names the active level (its nominal MHz), so it is the fallback
-            clk = pmc.get("sclk_mhz_profiled") or sclk_mhz
+            # / 8 / the kernel's duration, both from the SQ pass of the committed profile
+            clk = pmc.get("sclk_mhz_profiled")
             if clk:
                 floor_ms = pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (N_SIMD * clk * 1e6) * 1e3
                 valu = {"SQ_INSTS_VALU_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES_PER_INST,
-                        "simds": N_SIMD, "sclk_mhz": clk, "sclk_source": ("profile run: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration" if pmc.get("sclk_mhz_profiled")
-                                        else "sysfs pp_dpm_sclk level during the timed region"),
+                        "simds": N_SIMD, "sclk_mhz": clk, "sclk_source": "profile run: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration",
                         "issue_floor_ms": round(floor_ms, 3), "frac_of_issue_floor": round(floor_ms / agg_ms, 4),
                         "wave_cycles_active_issuewait_memwait": [pmc.get("sq_active_inst_any_frac_of_wave_cycles"),
                                                                  pmc.get("sq_wait_inst_any_frac_of_wave_cycles"),
@@ -613,7 +580,7 @@ def run_rank(args):
                           f"{16 if wide else 8} pixels per wave)" if fused else "sgm_paths_kernel (8-path aggregation)"),
                "limited_by": "valu issue",
                "kernel_ms": round(agg_ms, 4), "kernel_launches_timed": agg_n, "kernel_ms_back_to_back": round(agg_ms_b2b, 4),
-               "share_of_step": round(agg_ms / ms_per_step, 3),
+               "launches_per_step": launches_per_step, "share_of_step": round(agg_ms * launches_per_step / ms_per_step, 3),
                "valu": valu,
                "traffic_unit": "GB per launch (PMC)",
                "hbm_frac_of_peak": pmc.get("hbm_frac_of_peak") if pmc else None,
@@ -624,14 +591,40 @@ def run_rank(args):
                                                                             "launches_timed": we_n, "back_to_back": round(we_ms, 4)}}
                                                if fused else None),
                "frames_per_launch": agg_frames, "cells_per_launch": cells_launch,
-               "sclk_dpm_level_mhz_during_timed_region": sclk_mhz,
                "pmc": pmc}
+        # ---- the three big kernels of a part side by side: the byte-count convention (SURVEY 8d's share of the 16 B/cell), the
+        # real HBM utilisation and the VALU issue floor (both from the committed PMC profile of THESE kernel sources, else null)
+        def kernel_row(pmc_name, ms, bytes_per_cell, what):
+            if not ms or ms <= 0:
+                return None
+            row = {"what": what, "ms_per_launch": round(ms, 4), "launches_per_step": launches_per_step,
+                   "convention_bytes_per_cell": bytes_per_cell,
+                   "convention_frac": round(cells_launch * bytes_per_cell / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "hbm_frac_of_peak": None, "frac_of_issue_floor": None}
+            pk = pmc_view(agg_frames, ms, pmc_name)
+            if pk:
+                row["hbm_frac_of_peak"] = pk.get("hbm_frac_of_peak")
+                clk = pk.get("sclk_mhz_profiled")
+                if pk.get("SQ_INSTS_VALU") and clk:
+                    row["frac_of_issue_floor"] = round(pk["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (N_SIMD * clk * 1e6) * 1e3 / ms, 4)
+                    row["SQ_INSTS_VALU_per_launch"] = pk["SQ_INSTS_VALU"]
+            return row
+        kernels = None
+        if fused:
+            sum_ms = stages.get("sum_wta_left", 0.0) / launches_per_step
+            we_name = "sgm_we12_kernel" if D in (128, 192, 256) else "sgm_paths_kernel"
+            kernels = {dom_kernel: kernel_row(dom_kernel, agg_ms, agg_bytes, "N, NW, NE + S, SW, SE (in-step hipEvent pairs)"),
+                       we_name: kernel_row(we_name, we_ms_in_step if we_n else we_ms, AGG_BYTES_PER_CELL * 2.0 / 8.0, "W, E (in-step hipEvent pairs)"),
+                       ("sum_wta_trap_kernel" if D == 256 else "sum_wta_lr_kernel"):
+                           kernel_row("sum_wta_trap_kernel" if D == 256 else "sum_wta_lr_kernel", sum_ms, 4.0, "sum + left / right WTA + sub-pixel (stage-timed pass, overlap off)")}
         occ_txt = "occlusion heuristic + " if use_occ else ""
         result = {
             "metric": f"Mdisparities/s (HxWxD / s) VPP+rSGM at {H}x{W}xD={D}",
             "value": round(value, 1), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "ms_per_step_unpipelined": round(ms_unpipelined, 3) if ms_unpipelined else None, "higher_is_better": True,
+            "ms_per_step_unpipelined": round(ms_unpipelined, 3) if ms_unpipelined else None,
+            "ms_per_step_sustained": round(ms_sustained, 3) if ms_sustained else None, "sustained_steps": args.sustained_steps if ms_sustained else None,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u16",
             "data": "synthetic (uniform random u8)" if args.uniform_random else "synthetic",
             "config": {"workload": f"{H}x{W} RGB pair, {100 * P_HINTS:g}% hints, {occ_txt}VPP(rnd, wsize 3)+rSGM D={D} subpixel, "
@@ -653,9 +646,15 @@ def run_rank(args):
             # (hipEvent pairs on the launch stream), against the HBM3E peak; `traffic` = the launch's real HBM bytes (PMC).
             # It is a byte-count convention: the kernel is bound by instruction issue (`valu`), `hbm_frac_of_peak` is its
             # utilisation.  The whole step against the same peak (north_star's ">= 60 %") is `pipeline_roofline`.
-            "roofline": dict({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` names the real limiter: every fused kernel here is bound by VALU instruction issue, so `frac` (the contract's
+            # A/P against the HBM peak) is a byte-count convention, `frac_of_issue_floor` the kernel's distance from ITS bound
+            # and `hbm_frac_of_peak` its real memory utilisation.
+            "roofline": dict({"bound": "valu" if fused else "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4),
-                              "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None}, **dom),
+                              "frac_is": "algorithmic bytes (SURVEY 8d) / kernel time vs the HBM peak: a byte-count convention for an issue-bound kernel",
+                              "frac_of_issue_floor": valu["frac_of_issue_floor"] if valu else None,
+                              "traffic": pmc["hbm_GB_per_launch"] if pmc and "hbm_GB_per_launch" in pmc else None,
+                              "kernels": kernels}, **dom),
             "pipeline_roofline": {"what": "whole step at SURVEY 8d's algorithmic bytes, H*W*(16*D + 50) B per frame, vs the HBM3E peak "
                                           "(the figure north_star's 60 % is about; it prices the REFERENCE's dataflow, the build moves less: traffic)",
                                   "bytes_per_cell": PATH_BYTES_PER_CELL, "bytes_per_pixel": PATH_BYTES_PER_PIXEL,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/make_pmc_json.py <tag> <out.json> [--batch B]: per-kernel PMC summary of the passes tools/prof_round.sh left in
+"""tools/make_pmc_json.py <tag> <out.json> [--batch B] [--step-batch S] [--shape H W D]: per-kernel PMC summary of the passes tools/prof_round.sh left in
 gpurun_out/ (run in the build container, where git knows the commit).  Only launches at the profiled batch size are
 averaged (the bench also makes B=1 calls): they are told apart by the grid size of the dominant kernels.
 FETCH_SIZE is doubled (gfx950 under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md section HBM)."""
@@ -45,7 +45,9 @@ def big_avg(vals):
 def main():
     tag, out = sys.argv[1], sys.argv[2]
     batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 16   # frames per launch (a 32-frame step = 2 parts)
-    parts = int(sys.argv[sys.argv.index("--parts") + 1]) if "--parts" in sys.argv else 2
+    step_batch = int(sys.argv[sys.argv.index("--step-batch") + 1]) if "--step-batch" in sys.argv else 32   # frames per step of the profiled bench run
+    parts = int(sys.argv[sys.argv.index("--parts") + 1]) if "--parts" in sys.argv else -(-step_batch // batch)   # launches of a part-sized kernel per step
+    HH, WW, DD = ((int(v) for v in sys.argv[sys.argv.index("--shape") + 1:sys.argv.index("--shape") + 4]) if "--shape" in sys.argv else (bench.H, bench.W, bench.D))
     fe, wr, sq = passes(tag, "FETCH_SIZE"), passes(tag, "WRITE_SIZE"), passes(tag, "SQ")
     kern = {}
     for k in sorted(set(fe) | set(wr) | set(sq)):
@@ -82,7 +84,7 @@ def main():
     doc = {"hbm_GB_per_step": per_step, "note": "rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ set, each its own run) of "
                    "`python3 bench.py` by tools/prof_round.sh; per-launch averages over the full-batch launches, summed over the "
                    "chip.  hbm_GB_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB.  SQ_* cycle counters are quad-cycles summed over waves.",
-           "commit": commit, "kernel_source_sha": bench.kernel_source_sha(), "batch": batch, "parts_per_step": parts, "H": bench.H, "W": bench.W, "D": bench.D,
+           "commit": commit, "kernel_source_sha": bench.kernel_source_sha(), "batch": batch, "step_batch": step_batch, "parts_per_step": parts, "H": HH, "W": WW, "D": DD,
            "kernels": kern}
     json.dump(doc, open(out, "w"), indent=1)
     for k in ("sgm_vert4_kernel", "sgm_we12_kernel", "sum_wta_lr_kernel"):
