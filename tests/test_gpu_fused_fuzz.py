@@ -177,3 +177,75 @@ def test_batched_vpp_with_a_mask_random_parameters(engines, seed):
         oracle.init_rand(seed + f)
         lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], g_occ=occ[f], **ref_kw)
         assert np.array_equal(lo, lv[f]) and np.array_equal(ro, rv[f]), (seed, f, B, H, W, ref_kw)
+
+
+def _env_engine(**env):
+    import os
+    from vppstereo_amd.engine import Engine
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update({k: str(v) for k, v in env.items()})
+        return Engine()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# (engine environment, B, H, W, occlusion parameters): what the front stage of a PIPELINED call at dmax = 256 picks when the
+# previous call's sum / WTA kernel leaves little LDS (vpp_rsgm_one: front_lds_budget; vpp_kernels.hip: occ_test_kernel<NJ, 2>,
+# apply_l_bits_kernel<NW, 1>, r_rows_kernel in column segments).  Fewer than 6 frames: 8-path layout, uniform ring of 153 KB,
+# 6.5 KB left -> the small variants, rows of 450 / 333 / 211 columns = 3 / 2 / 2 segments of unequal width; 8 frames with
+# sum_trap1 / sum_trap0 (trapezoid ring without spare slots: 42 KB left, uniform ring: 6.5 KB): the fused layout's budgets;
+# the default (spare slots: nothing fits next to the kernel, the front stage keeps its stand-alone shapes).
+@pytest.mark.parametrize("env,B,H,W,occ", [
+    (dict(), 3, 20, 450, dict()),
+    (dict(), 5, 14, 333, dict(rx=17, ry=13, th_filter=0.5)),       # 238 window positions: occ_test_kernel<4, 2>
+    (dict(), 2, 18, 211, dict(rx=21, ry=19, l=1.0, g=0.25)),        # 420: the generic variant
+    (dict(VPPX_VERT=3, VPPX_VARIANT="sum_trap1"), 8, 10, 1500, dict()),
+    (dict(VPPX_VERT=3, VPPX_VARIANT="sum_trap0"), 8, 12, 420, dict(rx=17, ry=13)),
+    (dict(VPPX_VERT=3), 8, 12, 300, dict()),
+])
+def test_pipelined_front_stage_at_d256_matches_unpipelined_and_oracle(env, B, H, W, occ):
+    """Three back-to-back pipelined calls at dmax = 256 with the mask computed on the way: disparities, mask and patterned
+    pair equal the unpipelined engine bit for bit, and frame 0 / the last frame equal the CPU oracle."""
+    import torch
+    D = 256
+    eng, ref = _env_engine(**env), _env_engine(**env)
+    eng.set_pipeline(True)
+    dev = eng.device
+    b = synth.make_batch(B, H, W, D, 0.06, seed=9100 + W)
+    args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("left", "right", "hints")]
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    ev.record()
+    torch.cuda.synchronize()
+    got = []
+    for s in range(3):   # no synchronisation in between: the front stage of call s + 1 runs under call s's sum / WTA kernel
+        occ_o = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+        rv = torch.empty_like(lv)
+        o = eng.vpp_rsgm(*args, g_occ=dict(occ) if occ else "occlusion_heuristic", occ_out=occ_o, l_vpp=lv, r_vpp=rv, seed=40 + s,
+                         rsgm_kw=dict(dmax=D, subpixel=1), inputs_ready=ev)
+        got.append((o, occ_o, lv, rv))
+    eng.synchronize()
+    if "VPPX_VERT" in env:
+        assert eng.uses_vert() == 3
+    for s in range(3):
+        occ_o = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        lv = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+        rv = torch.empty_like(lv)
+        o = ref.vpp_rsgm(*args, g_occ=dict(occ) if occ else "occlusion_heuristic", occ_out=occ_o, l_vpp=lv, r_vpp=rv, seed=40 + s,
+                         rsgm_kw=dict(dmax=D, subpixel=1))
+        ref.synchronize()
+        for a, w, name in zip(got[s], (o, occ_o, lv, rv), ("disparity", "mask", "l_vpp", "r_vpp")):
+            assert torch.equal(a, w), (s, name)
+    for f in (0, B - 1):
+        conf = oracle.occlusion_heuristic(b["hints"][f], **occ)[1]
+        assert np.array_equal(conf, got[2][1][f].cpu().numpy()), f
+        oracle.init_rand(42 + f)
+        lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], g_occ=conf)
+        assert np.array_equal(lo, got[2][2][f].cpu().numpy()) and np.array_equal(ro, got[2][3][f].cpu().numpy()), f
+        assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D, subpixel=True), got[2][0][f].cpu().numpy()), f

@@ -987,7 +987,9 @@ __device__ __forceinline__ void we12_load_quad(u32 (&T)[4], const We12Lane &ln, 
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off, 16 * Q, 0);
         T[0] = v.x; T[1] = v.y; T[2] = v.z; T[3] = v.w;
     } else {     // steps x = Wp-1-4Q-i bring in cr[x - dbase - (DPL-1)]: descending, one word off a 16-byte boundary
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off, 4 * (Wp - DPL - 3 - 4 * Q), 0);
+        // (the constant part sits in the signed lane offset -- it stays positive: 512 guard words -- so that the scalar offset,
+        // which the hardware adds as an UNSIGNED 32-bit value, is never negative: 4Q <= Wp - 4)
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cr, ln.cr_off - 4 * (DPL + 3), 4 * (Wp - 4 * Q), 0);
         T[0] = v.w; T[1] = v.z; T[2] = v.y; T[3] = v.x;
     }
 }

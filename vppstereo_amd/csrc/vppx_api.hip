@@ -1262,7 +1262,9 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
     {   // what the front-stage kernels may use of a CU's LDS: next to the previous part's sum / WTA kernel when pipelined
         const size_t sum_lds = rsgm_sum_lds_bytes(ctx, rp->dmax, B >= VPPX_FUSED_MIN_FRAMES ? 4 : 8), cu_lds = 160 * 1024; // (the previous part has this part's shape)
         const size_t left_over = cu_lds > sum_lds + 512 ? cu_lds - sum_lds - 512 : 2048;
-        ctx->front_lds_budget = (piped && left_over < 64 * 1024) ? left_over : 64 * 1024;
+        // (less than 6 KB left -- D = 256 on the trapezoid ring with spare slots, whose 4 x 125 VGPRs per SIMD leave no registers
+        // either: nothing of the front stage can run NEXT to that kernel, so its kernels keep their efficient shapes and run in its tail)
+        ctx->front_lds_budget = (piped && left_over < 64 * 1024 && left_over >= 6 * 1024) ? left_over : 64 * 1024;
     }
     stage_begin(ctx);
     if (op) { // test.py:154: g_occ = occlusion_heuristic(hints)[1]
