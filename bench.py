@@ -143,6 +143,29 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def pin_to_gpu_numa(torch, dev_index):
+    """One process per GPU: keep the rank's host threads on the NUMA node its GPU hangs off (PCIe root complex), so that the
+    launch thread and RCCL's proxy thread do not wander over the sockets of a 2-socket host.  Returns what was done."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return {"pci": bdf, "numa_node": node, "pinned": False}
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "pinned": bool(cpus), "cpus": len(cpus)}
+    except Exception as e:  # noqa: BLE001
+        return {"pinned": False, "why": f"{type(e).__name__}: {e}"[:80]}
+
+
 def spawn_check(args):
     """Launcher self-test (CPU, gloo): every rank reports its frame plan, rank 0 prints what it saw."""
     import torch
@@ -356,6 +379,7 @@ def run_rank(args):
     ndev = torch.cuda.device_count()
     dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)  # dry runs: several ranks on one GPU
     torch.cuda.set_device(dev_index)
+    affinity = pin_to_gpu_numa(torch, dev_index) if world > 1 else None
     backend = args.backend or ("nccl" if world <= ndev else "gloo")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -416,16 +440,22 @@ def run_rank(args):
         k = nstep[0] % n_out
         nstep[0] += 1
         if pending[k] is not None:
+            t0 = time.perf_counter()
             pending[k].wait()
+            gather_wait[0] += time.perf_counter() - t0
             pending[k] = None
         local_step(outs[k], use_occ)
         if world > 1 and not args.no_gather:
             pending[k] = vdist.gather_disparities_async(outs[k], n_total, dst=0)  # every rank calls step() equally often
 
+    gather_wait = [0.0]   # host seconds the step loop spent waiting for a gather (the exposed part of the exchange)
+
     def drain():
         for k in range(n_out):
             if pending[k] is not None:
+                t0 = time.perf_counter()
                 pending[k].wait()
+                gather_wait[0] += time.perf_counter() - t0
                 pending[k] = None
 
     if world > 1 and not args.no_gather:
@@ -470,17 +500,23 @@ def run_rank(args):
     drain()
     eng.agg_kernel_ms(0)  # reset: the hipEvent pairs around the aggregation launches of the timed steps only
     eng.we_kernel_ms(0)
+    gather_wait[0] = 0.0
     dt_local = timed(args.steps, step)
+    gather_ms_local = gather_wait[0] / args.steps * 1e3
     eng.status()   # raises if a fused aggregation launch of the timed region lost its lock step (its disparities would be void)
     dt = dt_local
     rank_ms = [dt_local / args.steps * 1e3]
+    rank_gather_ms = [gather_ms_local]
+    rank_numa = [affinity.get("numa_node") if affinity and affinity.get("pinned") else None]
     if world > 1:
         cdev = dev if backend == "nccl" else "cpu"
-        t = torch.tensor([dt_local], dtype=torch.float64, device=cdev)
+        t = torch.tensor([dt_local, gather_ms_local, float(rank_numa[0]) if rank_numa[0] is not None else -1.0], dtype=torch.float64, device=cdev)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
-        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
-        dt = max(float(x.item()) for x in allt)
+        rank_ms = [float(x[0].item()) / args.steps * 1e3 for x in allt]
+        rank_gather_ms = [float(x[1].item()) for x in allt]
+        rank_numa = [int(x[2].item()) if x[2].item() >= 0 else None for x in allt]
+        dt = max(float(x[0].item()) for x in allt)
     if args.graph:
         assert eng.graph_replays() > 0, "--graph was given but no call was served by a graph replay"
     # power steady state: the timed region is a fraction of a second on a chip that clocks by its power budget; the same loop
@@ -640,7 +676,9 @@ def run_rank(args):
                                               "ms_per_step_unpipelined is the same loop with the overlap off")},
             "ranks": {"launched": args.gpus, "seen": dist.get_world_size() if world > 1 else 1,
                       "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
-                      "ms_per_step_per_rank": [round(x, 3) for x in rank_ms]},
+                      "ms_per_step_per_rank": [round(x, 3) for x in rank_ms],
+                      "gather_wait_ms_per_step_per_rank": [round(x, 3) for x in rank_gather_ms] if world > 1 else None,
+                      "numa_node_per_rank": rank_numa if world > 1 else None},
             # The dominant kernel (bench contract): SURVEY 8d's algorithmic bytes of the launch -- 10 B/cell for the 8-path
             # aggregation, pro rata for the paths the launch carries -- over its average duration inside the timed steps
             # (hipEvent pairs on the launch stream), against the HBM3E peak; `traffic` = the launch's real HBM bytes (PMC).
