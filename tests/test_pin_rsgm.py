@@ -70,3 +70,41 @@ def test_hip_drop_in_passes_every_stage_check():
     lines = []
     ran, failed = pin_rsgm.run(oracle, None, {"vppstereo_amd.pyrSGM": hip_natives}, seed=5, log=lines.append)
     assert failed is None and ran == 8, "\n".join(lines)
+
+
+def _stub_module(dirname, altered):
+    """A stand-in `pyrSGM` for the round trip: the oracle's natives under the real module's name (optionally with a cost volume
+    that leaves d > x at 0).  The stand-alone script itself imports nothing of this repository; the STUB does, in place of the
+    compiled extension a maintainer has."""
+    with open(os.path.join(dirname, "pyrSGM.py"), "w") as f:
+        f.write("import sys\nsys.path.insert(0, %r)\nimport oracle as _o\n" % ROOT)
+        f.write("census5x5_SSE = _o.census5x5_SSE\naggregate_SSE = _o.aggregate_SSE\nmatchWTA_SSE = _o.matchWTA_SSE\n"
+                "matchWTARight_SSE = _o.matchWTARight_SSE\nsubPixelRefine = _o.subPixelRefine\nmedian3x3_SSE = _o.median3x3_SSE\n")
+        if altered:
+            f.write("def costMeasureCensus5x5_xyd_SSE(cl, cr, dsi, w, h, dmax, n=1):\n"
+                    "    _o.costMeasureCensus5x5_xyd_SSE(cl, cr, dsi, w, h, dmax, n)\n"
+                    "    for x in range(min(w, dmax)):\n        dsi[:, x, x + 1:] = 0\n")
+        else:
+            f.write("costMeasureCensus5x5_xyd_SSE = _o.costMeasureCensus5x5_xyd_SSE\n")
+
+
+@pytest.mark.parametrize("altered", [False, True])
+def test_dump_and_from_round_trip(tmp_path, altered):
+    """--dump DIR -> the stand-alone run_reference.py run where "pyrSGM" exists -> --from DIR: whoever has the submodule needs
+    nothing of this repository, whoever has this repository needs nothing of the submodule."""
+    d = str(tmp_path / "pin")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pin_rsgm.py"), "--dump", d, "--seed", "4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and os.path.exists(os.path.join(d, "inputs.npz")), r.stdout + r.stderr
+    src = open(os.path.join(d, "run_reference.py")).read()
+    assert "vppstereo_amd" not in src.split('"""')[2] and "import oracle" not in src   # no repo import in the script's code
+    stub = str(tmp_path / "stub")
+    os.makedirs(stub)
+    _stub_module(stub, altered)
+    r = subprocess.run([sys.executable, "run_reference.py", "--pyrsgm-path", stub], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and os.path.exists(os.path.join(d, "outputs.npz")), r.stdout + r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pin_rsgm.py"), "--from", d], capture_output=True, text=True, timeout=300)
+    if altered:
+        assert r.returncode == 1 and "first differing stage: 4" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 0 and "stage checks agree with the recorded reference outputs" in r.stdout, r.stdout + r.stderr
+        assert r.stdout.count("PASS") >= 8
