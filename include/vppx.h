@@ -262,6 +262,14 @@ int vppx_vpp_rsgm_dev(vppx_ctx *ctx, const VppxVppParams *vp, const VppxRsgmPara
 int vppx_occ_vpp_rsgm_dev(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B,
                           int H, int W, int C, const uint8_t *left, const uint8_t *right, const float *g, uint8_t *conf_out,
                           uint8_t *l_vpp, uint8_t *r_vpp, float *disp_out);
+/* The same for HOST arrays, one frame or a batch: test.py:154-225 in one call.  The pair, the hints and a caller's mask go up
+ * once, the disparities -- and, where the pointers are not NULL, the mask
+ * (op != NULL: computed on the way, test.py:154), and the patterned pair -- come down once; synchronous.  op == NULL: g_occ
+ * (may be NULL) is the caller's mask.  draws_out (may be NULL, [B]): rand() draws each frame consumed (0 for maxDistance or
+ * when the call ran in parts), for callers that continue a libc-like stream (vppx_rand_advance). */
+int vppx_occ_vpp_rsgm_host(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
+                           int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                           uint8_t *conf_out, uint8_t *l_vpp_out, uint8_t *r_vpp_out, float *disp_out, uint64_t *draws_out);
 
 /* ---- hand-off to the deep front-ends (test.py:179-200) -------------------------------------- */
 /* uint8 [B,H,W,C] (device) -> [B,C,Hq,Wq] float32 (dst_is_bf16 = 0) or bfloat16 (1) in [0,1]

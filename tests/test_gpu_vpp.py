@@ -334,3 +334,29 @@ def test_occlusion_mask_single_launch_kernel(h, w, p):
         for f in range(3):
             want = oracle.occlusion_heuristic(b["hints"][f], **kw)[1]
             assert np.array_equal(got[f], want), (kw, f, int((got[f] != want).sum()))
+
+
+@pytest.mark.parametrize("maskocc,method", [(True, "rnd"), (False, "rnd"), (True, "maxDistance")])
+def test_run_frame_equals_the_three_drop_in_calls(maskocc, method):
+    """vppstereo_amd.pipeline.run_frame (one call, one upload: vppx_occ_vpp_rsgm_host) against filter.occlusion_heuristic +
+    vpp_standalone.vpp + rsgm.compute_rsgm called one after the other (test.py:154-225), twice in a row: same disparities,
+    same patterned pair, same mask, and the same position of the shared random stream afterwards."""
+    from vppstereo_amd import filter as vfilter, pipeline, rsgm, vpp_standalone
+    D = 64
+    fr = synth.make_frame(60, 150, D, 0.05, seed=31)
+    kw = dict(wsize=5, blending=0.3, c_occ=0.2, method=method)
+    vpp_standalone.init_rand(7)
+    want = []
+    for _ in range(2):
+        conf = vfilter.occlusion_heuristic(fr["hints"])[1] if maskocc else None
+        lc, rc = vpp_standalone.vpp(fr["left"], fr["right"], fr["hints"], g_occ=conf, **kw)
+        want.append((rsgm.compute_rsgm(fr["left"], lc, rc, dmax=D, p1=9), lc, rc, conf))
+    vpp_standalone.init_rand(7)
+    for i in range(2):
+        d, lc, rc, conf = pipeline.run_frame(fr["left"], fr["right"], fr["hints"], maskocc=maskocc, vpp_kw=kw, rsgm_kw=dict(dmax=D, p1=9),
+                                             return_patterns=True)
+        assert np.array_equal(d, want[i][0]) and np.array_equal(lc, want[i][1]) and np.array_equal(rc, want[i][2]), i
+        if maskocc:
+            assert np.array_equal(conf, want[i][3])
+    d2 = pipeline.run_frame(fr["left"], fr["right"], np.zeros_like(fr["hints"]), maskocc=maskocc, rsgm_kw=dict(dmax=D))   # no hints at all
+    assert np.array_equal(d2, rsgm.compute_rsgm(fr["left"], fr["left"], fr["right"], dmax=D))

@@ -27,7 +27,7 @@ EXPORTS = [
     "vppx_rand_stream", "vppx_rand_state", "vppx_rand_advance", "vppx_virtual_projection_scan_rnd", "vppx_virtual_projection_scan_max_dist", "vppx_vpp_host",
     "vppx_vpp_dev", "vppx_vpp_last_draws", "vppx_census5x5", "vppx_cost_census5x5_xyd", "vppx_aggregate", "vppx_aggregate_img", "vppx_match_wta",
     "vppx_match_wta_right", "vppx_subpixel_refine", "vppx_median3x3", "vppx_rsgm_host", "vppx_rsgm_dev",
-    "vppx_vpp_rsgm_dev", "vppx_rsgm_post_dev", "vppx_occ_vpp_rsgm_dev", "vppx_inputs_ready_event", "vppx_u8_to_nchw_dev", "vppx_psmnet_cost_volume_dev", "vppx_raft_corr_modulate_dev", "vppx_kitti_disp_decode_dev", "vppx_png_decode_dev", "vppx_pfm_decode_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_occlusion_heuristic_full_host", "vppx_occlusion_heuristic_full_dev", "vppx_set_graph_mode", "vppx_graph_replays", "vppx_time_aggregate", "vppx_agg_kernel_ms", "vppx_we_kernel_ms", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert", "vppx_last_call_parts", "vppx_fused_pixels_per_wave", "vppx_batch_quantum",
+    "vppx_vpp_rsgm_dev", "vppx_rsgm_post_dev", "vppx_occ_vpp_rsgm_dev", "vppx_occ_vpp_rsgm_host", "vppx_inputs_ready_event", "vppx_u8_to_nchw_dev", "vppx_psmnet_cost_volume_dev", "vppx_raft_corr_modulate_dev", "vppx_kitti_disp_decode_dev", "vppx_png_decode_dev", "vppx_pfm_decode_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_occlusion_heuristic_full_host", "vppx_occlusion_heuristic_full_dev", "vppx_set_graph_mode", "vppx_graph_replays", "vppx_time_aggregate", "vppx_agg_kernel_ms", "vppx_we_kernel_ms", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert", "vppx_last_call_parts", "vppx_fused_pixels_per_wave", "vppx_batch_quantum",
     "vppx_enable_stage_timing", "vppx_get_stage_ms", "vppx_stage_name",
 ]
 
@@ -133,6 +133,7 @@ def load():
         lib.vppx_rsgm_post_dev.argtypes = [vp, i, i, i, vp, vp, i, vp]
         lib.vppx_vpp_rsgm_dev.argtypes = [vp, pv, pr, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
         po = C.POINTER(VppxOccParams)
+        lib.vppx_occ_vpp_rsgm_host.argtypes = [vp, po, pv, pr, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
         lib.vppx_occ_params_default.argtypes = [po]
         lib.vppx_occ_params_default.restype = None
         lib.vppx_occ_vpp_rsgm_dev.argtypes = [vp, po, pv, pr, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]

@@ -426,6 +426,10 @@ extern "C" int vppx_get_stage_ms(vppx_ctx *ctx, float *ms, int max_n)
 // ---------------------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------------------
+// Host <-> device copies of the host-pointer entry points: straight from / to the caller's (pageable) arrays.  (Round 5 measured
+// a pinned staging arena owned by the context -- memcpy into it, asynchronous DMA from it, results copied out after the
+// synchronisation: occlusion_heuristic + vpp + compute_rsgm of one 540x960x192 frame 1.49 -> 1.89 ms, the fused host entry
+// 1.03 -> 1.13 ms: the runtime's own staging of pageable copies is faster than an extra pass over the data on one core.)
 static int upload(vppx_ctx *ctx, WsSlot s, const void *host, size_t bytes, void **dev)
 {
     int rc = ws_reserve(ctx, s, bytes, dev);
@@ -1327,6 +1331,65 @@ extern "C" int vppx_occ_vpp_rsgm_dev(vppx_ctx *ctx, const VppxOccParams *op, con
     const int rc = vpp_rsgm_entry(ctx, op, vp, rp, B, H, W, C, left, right, g, nullptr, conf_out, l_vpp, r_vpp, disp_out);
     ctx->inputs_ev = nullptr;
     return rc;
+}
+
+// test.py:154-225 for host arrays in ONE call: the pair, the hints (and a caller's mask) go up once, the disparities (and, on
+// request, the mask and the patterned pair) come down once; nothing is uploaded three times as with filter.occlusion_heuristic
+// + vpp_standalone.vpp + rsgm.compute_rsgm called one after the other.  op != NULL computes the mask on the way (--maskocc),
+// else g_occ (may be NULL) is the caller's.  draws_out (may be NULL, [B]): rand() draws each frame consumed, so that a
+// single-frame caller can advance the libc-like stream exactly like vpp() does.
+extern "C" int vppx_occ_vpp_rsgm_host(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H,
+                                      int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
+                                      uint8_t *conf_out, uint8_t *l_vpp_out, uint8_t *r_vpp_out, float *disp_out, uint64_t *draws_out)
+{
+    int rc;
+    VPPX_ENTER(ctx);
+    if (!vp || !rp || !left || !right || !g || !disp_out) { vppx_set_error("vppx_occ_vpp_rsgm_host: NULL argument"); return VPPX_E_INVALID_ARG; }
+    if ((rc = check_frames(B, H, W, C))) return rc;
+    const size_t nb = (size_t)B * H * W * C, np = (size_t)B * H * W;
+    void *dl, *dr, *dg, *docc = nullptr, *dconf = nullptr, *dlv = nullptr, *drv = nullptr, *dout;
+    // the hints go up first and the occlusion heuristic is queued at once: its kernels run while the host is busy with the
+    // (pageable, i.e. host-blocking) uploads of the pair
+    if ((rc = upload(ctx, WS_STAGE_C, g, np * sizeof(float), &dg))) return rc;
+    if (op) {
+        float *omap;
+        if ((rc = ws_get(ctx, WS_OCC_OMAP, np, &omap))) return rc;
+        if ((rc = ws_reserve(ctx, WS_STAGE_D, np, &dconf))) return rc;
+        ctx->front_lds_budget = 64 * 1024;
+        if ((rc = occ_launch(ctx, B, H, W, (const float *)dg, op->rx, op->ry, op->l, op->g, op->th_conf, op->th_filter, omap, (u8 *)dconf))) return rc;
+        docc = dconf; // from here on a given mask
+        if (!conf_out) dconf = nullptr;
+    } else if (g_occ && (rc = upload(ctx, WS_STAGE_D, g_occ, np, &docc))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_A, left, nb, &dl))) return rc;
+    if ((rc = upload(ctx, WS_STAGE_B, right, nb, &dr))) return rc;
+    if (l_vpp_out && (rc = ws_reserve(ctx, WS_STAGE_E, nb, &dlv))) return rc;
+    if (r_vpp_out && (rc = ws_reserve(ctx, WS_STAGE_F, nb, &drv))) return rc;
+    if ((rc = ws_reserve(ctx, WS_HANDOFF_H, np * sizeof(float), &dout))) return rc;
+    for (int attempt = 0;; attempt++) {
+        const unsigned serial_before = ctx->v3.serial;
+        rc = vpp_rsgm_entry(ctx, nullptr, vp, rp, B, H, W, C, (const u8 *)dl, (const u8 *)dr, (const float *)dg, (const u8 *)docc, nullptr,
+                            (u8 *)dlv, (u8 *)drv, (float *)dout);
+        ctx->inputs_ev = nullptr;
+        if (rc) return rc;
+        if ((rc = download(ctx, disp_out, dout, np * sizeof(float)))) return rc;
+        if (dconf && (rc = download(ctx, conf_out, dconf, np))) return rc;
+        if (dlv && (rc = download(ctx, l_vpp_out, dlv, nb))) return rc;
+        if (drv && (rc = download(ctx, r_vpp_out, drv, nb))) return rc;
+        std::vector<unsigned long long> tot;
+        if (draws_out && vp->method == VPPX_METHOD_RND && ctx->ws[WS_FRAME_TOT].p && ctx->last_parts == 1) {
+            tot.resize((size_t)B * 2);
+            VPPX_HIP(hipMemcpyAsync(tot.data(), ctx->ws[WS_FRAME_TOT].p, tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        VPPX_HIP(hipStreamSynchronize(ctx->stream));
+        if (draws_out)
+            for (int f = 0; f < B; f++) draws_out[f] = tot.empty() ? 0 : tot[2 * f];
+        // like vppx_rsgm_host: a lost lock step of THIS call is repeated on the line-parallel kernel, an earlier call's is reported
+        if ((rc = lockstep_check(ctx)) == 0) break;
+        const unsigned s = ctx->lockstep_last_serial;
+        const bool mine = (unsigned)(s - serial_before - 1u) < (unsigned)(ctx->v3.serial - serial_before);
+        if (!mine || attempt > 0) return rc;
+    }
+    return 0;
 }
 
 // Batches larger than one round of the lock-step kernel are run as consecutive parts of one round each ("batch quantum":
