@@ -9,7 +9,7 @@ echo "[" > $out
 first=1
 for r in $(seq 1 $rounds); do
     for s in $settings; do
-        env ${s//,/ } python3 bench.py --no-other-configs --cpu-frames 0 "$@" > gpurun_out/ab.tmp 2> gpurun_out/ab.err
+        env ${s//,/ } python3 bench.py --sustained-steps 0 --no-other-configs --cpu-frames 0 "$@" > gpurun_out/ab.tmp 2> gpurun_out/ab.err
         [ $first = 1 ] || echo "," >> $out
         first=0
         line=$(grep '^{' gpurun_out/ab.tmp | tail -1)
