@@ -21,7 +21,7 @@ def passes(tag, name):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{name}", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            k = re.split(r"[<(]", re.sub(r"^void ", "", r["Kernel_Name"]))[0]
+            k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]   # template arguments kept: variants of a kernel are told apart
             acc[k][r["Counter_Name"]].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
             try:
                 acc[k]["_dur_ns"].append((int(r.get("Grid_Size", 0) or 0), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
@@ -50,7 +50,24 @@ def main():
     HH, WW, DD = ((int(v) for v in sys.argv[sys.argv.index("--shape") + 1:sys.argv.index("--shape") + 4]) if "--shape" in sys.argv else (bench.H, bench.W, bench.D))
     fe, wr, sq = passes(tag, "FETCH_SIZE"), passes(tag, "WRITE_SIZE"), passes(tag, "SQ")
     kern = {}
-    for k in sorted(set(fe) | set(wr) | set(sq)):
+    # of the template variants of one kernel keep the one that carries the most work (total time in the SQ pass): the timed loop's
+    weight = {}
+    for k in set(fe) | set(wr) | set(sq):
+        src = fe.get(k, {}).get("FETCH_SIZE") or sq.get(k, {}).get("SQ_INSTS_VALU") or wr.get(k, {}).get("WRITE_SIZE") or []
+        dur = sq.get(k, {}).get("_dur_ns")
+        if dur:   # total time of the variant's launches in the SQ pass
+            weight[k] = sum(v for _, v in dur)
+            continue
+        by = collections.defaultdict(int)
+        for g, _ in src:
+            by[g] += 1
+        weight[k] = max((g * n for g, n in by.items()), default=0)
+    best = {}
+    for k, w in weight.items():
+        short = k.split("<")[0]
+        if short not in best or w > weight[best[short]]:
+            best[short] = k
+    for k in sorted(best.values()):
         d = {}
         if "FETCH_SIZE" in fe.get(k, {}):
             d["FETCH_SIZE_KB"], d["launches"] = big_avg(fe[k]["FETCH_SIZE"])
@@ -70,7 +87,8 @@ def main():
             for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
                 if c in d:
                     d[c.lower() + "_frac_of_wave_cycles"] = round(d[c] / d["SQ_WAVE_CYCLES"], 3)
-        kern[k] = {a: (round(b, 4 if a.startswith('kernel_ms') else (3 if a.endswith('_cycles') or a.startswith('hbm') else 1)) if isinstance(b, float) else b) for a, b in d.items()}
+        d["variant"] = k
+        kern[k.split("<")[0]] = {a: (round(b, 4 if a.startswith('kernel_ms') else (3 if a.endswith('_cycles') or a.startswith('hbm') else 1)) if isinstance(b, float) else b) for a, b in d.items()}
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
     except Exception:
