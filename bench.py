@@ -740,7 +740,7 @@ def run_rank(args):
                                          375, 1242, 192, 0.05, cfg3_q, tensors=t3))
             del t3, b3
             result["other_configs"] = cfg3 + [
-                other_config(eng, torch, synth, "cfg5: 1536x2048 indoor pairs, 1% hints, D=256, 8 frames per step", 1536, 2048, 256, 0.01, 8, steps=3, warmup=1),
+                other_config(eng, torch, synth, "cfg5: 1536x2048 indoor pairs, 1% hints, D=256, 8 frames per step", 1536, 2048, 256, 0.01, 8, steps=4, warmup=2),
                 {"config": "cfg2 literal: one 540x960 pair per call, D=192", "ms_per_frame": round(b1_ms, 4),
                  "Mdisparities_per_s": round(H * W * D / b1_ms / 1e3, 1),
                  "roofline_frac": round(H * W * D / b1_ms / 1e3 * 1e6 * (PATH_BYTES_PER_CELL + PATH_BYTES_PER_PIXEL / D) / 1e9 / HBM_PEAK_GBS, 4)},
