@@ -448,10 +448,12 @@ def test_pipelined_stream_of_small_batches_starts_the_next_front_stage_early():
             assert torch.equal(outs[i][rep], refs[i]), (rep, i, shapes[i])
 
 
-@pytest.mark.parametrize("B", [9, 26])
+@pytest.mark.parametrize("B", [9, 20, 26])
 def test_full_size_odd_batches_take_the_fused_layout(B):
     """Any number of frames from 8 on takes the fused layout at full size (the grid is rounded up to whole rounds of 8
-    groups, ghost groups exit): 9 and 26 frames of 540 x 960 x 192, two pipelined steps, equal the 8-path layout bit for bit."""
+    groups, ghost groups exit): 9, 20 and 26 frames of 540 x 960 x 192, two pipelined steps, equal the 8-path layout bit for bit.
+    9 frames and the 10-frame part of 26 are under-filled lock-step launches (W/E runs next to them on the side stream); 20
+    frames are one part of a whole round + 4: two lock-step launches, W/E next to the second (rsgm_vert3_plan)."""
     import torch
     H, W, D = 540, 960, 192
     eng = _engine()

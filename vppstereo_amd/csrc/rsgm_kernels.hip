@@ -2260,38 +2260,73 @@ static int v3_rec_dwords(bool wide, int D)
 }
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D)
 {
-    // (sized for whichever of the two kernels needs more, + the record of zeros)
+    // (sized for whichever of the two kernels needs more, + the record of zeros; twice: a batch may run as two launches)
+    const size_t narrow = (size_t)2 * B * (Wp / 8) * v3_rec_dwords(false, D);
+    const size_t wide = (size_t)2 * B * (Wp / 16) * v3_rec_dwords(true, D);
+    return ((narrow > wide ? narrow : wide) + 128) * sizeof(u32);
+}
+static size_t v3_xbuf_bytes_one(int B, int Wp, int D)
+{
     const size_t narrow = (size_t)2 * B * (Wp / 8) * v3_rec_dwords(false, D);
     const size_t wide = (size_t)2 * B * (Wp / 16) * v3_rec_dwords(true, D);
     return ((narrow > wide ? narrow : wide) + 64) * sizeof(u32);
 }
 
-int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
-                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev)
+// How a batch meets the rounds of the lock-step kernel: *whole_frames = the frames of its whole rounds (0 when the batch is at
+// most one round), and whether what is left -- the remainder, or a batch smaller than a round -- fills less than about two
+// thirds of a round's block slots.  Such a launch leaves SIMDs idle for its whole duration (78 waves of a 1248-column group on
+// an XCD's 128 SIMDs; two 8-pixel groups of a 960-column frame on 512 slots): the W/E launch of the same part, which needs
+// nothing of it, then runs NEXT to it (run_aggregation).  Next to a full round it costs more than it hides (NOTEBOOK).
+void rsgm_vert3_plan(const vppx_ctx *ctx, int B, int Wp, int D, int *whole_frames, bool *rest_underfilled)
 {
+    *whole_frames = 0;
+    *rest_underfilled = false;
+    const int fpr = rsgm_vert3_frames_per_round(ctx, Wp, D); // frames per round of the 16-pixel kernel
+    if (fpr <= 0 || !ctx->v3.ok) return;
+    int rest = B;
+    if (v3_wide(ctx, B, Wp, D) && B > fpr && B % fpr != 0) {
+        *whole_frames = B - B % fpr;
+        rest = B % fpr;
+    } else if (B >= fpr) {
+        return; // whole rounds only
+    }
+    *rest_underfilled = 3 * rest <= 2 * fpr;
+}
+
+// One launch of the fused vertical kernel over the frames [f0, f0 + nB) of a batch of B_total (the volume's pass stride);
+// first: the batch's first launch (new serial, records cleared).
+int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int f0, int nB, int Hp, int Wp, int D, const u8 *gray,
+                            const u32 *cl, const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev)
+{
+    if (f0 == 0) {
+        ++ctx->v3.serial; // one serial per aggregation, whatever the number of launches (void_if_lost_kernel)
+        if (ctx->v3.serial == 0) ++ctx->v3.serial;
+        // no record of an earlier launch may match: cleared here, unless a pipelined call's front_end has already queued the
+        // clear on this stream behind the previous launch (vppx_api.hip; never inside a graph capture: a replayed graph must
+        // carry its own clear)
+        const size_t xbytes = rsgm_vert3_xbuf_bytes(B_total, Wp, D);
+        if (!(ctx->xbuf_cleared && !ctx->capturing && ctx->xbuf_last == (void *)xbuf && ctx->xbuf_last_bytes >= xbytes && stream == ctx->stream))
+            VPPX_HIP(hipMemsetAsync(xbuf, 0, xbytes, stream));
+        ctx->xbuf_last = (void *)xbuf;
+        ctx->xbuf_last_bytes = xbytes;
+        ctx->xbuf_cleared = false;
+    } else {
+        xbuf += v3_xbuf_bytes_one(f0, Wp, D) / sizeof(u32); // a second launch's records lie behind the first's
+    }
+    const size_t fpix = (size_t)f0 * Hp * Wp;
     Vert3Args a;
-    a.gray = gray; a.cl = cl; a.cr = cr; a.p2lut = p2lut; a.sv = sv; a.xbuf = xbuf; a.err = err; a.err_dev = err_dev;
-    a.B = B; a.Hp = Hp; a.Wp = Wp;
+    a.gray = gray + fpix; a.cl = cl + fpix; a.cr = cr + fpix; a.p2lut = p2lut; a.sv = sv + fpix * D; a.xbuf = xbuf; a.err = err; a.err_dev = err_dev;
+    a.B = nB; a.Hp = Hp; a.Wp = Wp;
     a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (see rsgm_launch_paths); keeps the small-value update in range
-    const bool wide = v3_wide(ctx, B, Wp, D);
-    ctx->v3.last_ppw = wide ? 16 : 8;
+    const bool wide = v3_wide(ctx, nB, Wp, D);
+    if (f0 == 0) ctx->v3.last_ppw = wide ? 16 : 8;
     a.nwv = wide ? Wp / 16 : Wp / 8;
     a.nbg = (a.nwv + 3) / 4;
-    a.vol_elems = (size_t)B * Hp * Wp * D;
+    a.vol_elems = (size_t)B_total * Hp * Wp * D;
     a.timeout_ticks = (long long)ctx->v3.timeout_ms * (long long)(ctx->v3.wall_khz > 0 ? ctx->v3.wall_khz : 100000);
     a.spin_limit = ctx->v3.spin_limit;
-    a.serial = ++ctx->v3.serial;
-    if (a.serial == 0) a.serial = ++ctx->v3.serial;
-    // no record of an earlier launch may match: cleared here, unless a pipelined call's front_end has already queued the
-    // clear on this stream behind the previous launch (vppx_api.hip; never inside a graph capture: a replayed graph must
-    // carry its own clear)
-    const size_t xbytes = rsgm_vert3_xbuf_bytes(B, Wp, D);
-    if (!(ctx->xbuf_cleared && !ctx->capturing && ctx->xbuf_last == (void *)xbuf && ctx->xbuf_last_bytes >= xbytes && stream == ctx->stream))
-        VPPX_HIP(hipMemsetAsync(xbuf, 0, xbytes, stream));
-    ctx->xbuf_last = (void *)xbuf;
-    ctx->xbuf_last_bytes = xbytes;
-    ctx->xbuf_cleared = false;
-    const dim3 grid((unsigned)((2 * B + 7) / 8 * 8 * a.nbg)); // whole rounds of 8 groups; groups >= 2B exit at once
+    a.serial = ctx->v3.serial;
+    const dim3 grid((unsigned)((2 * nB + 7) / 8 * 8 * a.nbg)); // whole rounds of 8 groups; groups >= 2 nB exit at once
     if (wide && D == 64) sgm_vert4_kernel<16><<<grid, 256, 0, stream>>>(a);
     else if (wide && D == 128) sgm_vert4_kernel<32><<<grid, 256, 0, stream>>>(a);
     else if (wide && D == 192) sgm_vert4_kernel<48><<<grid, 256, 0, stream>>>(a);
@@ -2302,6 +2337,12 @@ int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, 
     else sgm_vert3_kernel<32><<<grid, 256, 0, stream>>>(a);
     VPPX_CHECK_LAUNCH();
     return 0;
+}
+
+int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
+                      const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev)
+{
+    return rsgm_launch_vert3_range(ctx, stream, B, 0, B, Hp, Wp, D, gray, cl, cr, p2lut, p1, sv, xbuf, err, err_dev);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -184,6 +184,7 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
             if (has("sum_gl8")) ctx->knobs.sum_gl8 = 1;
             if (has("sum_trap0")) ctx->knobs.sum_trap = 0;
             if (has("sum_trap1")) ctx->knobs.sum_trap = 1;
+            if (has("we_after")) ctx->knobs.we_next = 0;
 #ifdef VPPX_EXPERIMENT
             if (has("pipe_mid")) ctx->pipe_mid = true; // the next front stage starts behind the vertical kernel, next to W/E (measured: 9.16 -> 9.6 ms per step)
             const size_t sb = v.find("sum_blocks=");
@@ -694,6 +695,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
         // them -- 16 or 8 rows per wave, the right-image census window kept in registers and shifted by one word per step:
         // 19 instead of 26 instructions per pixel, bit-exact -- and measured 1.88-2.10 ms (16 rows, 168 VGPRs: 2-3 waves per
         // SIMD cannot cover the walk's dependent chain) and 2.6 ms (8 rows: 96 VGPRs only with spills) against 1.94-2.00.)
+        bool we_launched = false; // (launch_vert has run W/E next to its under-filled launch)
         auto launch_we = [&]() -> int {
             // event pairs around this launch too: inside a step it follows a run of small kernels (or the previous step's
             // post stage) and has been seen to take longer than when it is re-launched back to back
@@ -734,7 +736,30 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 if ((rc = ws_get(ctx, WS_V3ERR, (size_t)4, &err_dev))) return rc;
                 if (fresh) VPPX_HIP(hipMemsetAsync(err_dev, 0, 16, st));
             }
-            const int r = rsgm_launch_vert3(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev);
+            // A batch of whole rounds + a remainder runs as two launches, and W/E runs NEXT to a launch that leaves most of an
+            // XCD's SIMDs idle (rsgm_vert3_plan): the remainder, or a batch well below one round.  W/E needs nothing of the
+            // vertical kernel (other volumes, the same read-only images), so the order is free; next to a FULL round it costs
+            // more than it hides (NOTEBOOK: 6.1 -> 7.1 ms), next to 78 waves on 128 SIMDs it has the idle ones.
+            int whole = 0;
+            bool rest_under = false;
+            if (which == 0 && ctx->knobs.we_next && st == ctx->stream && !we_launched) rsgm_vert3_plan(ctx, g.B, g.Wp, g.D, &whole, &rest_under);
+            int r;
+            if (!rest_under) {
+                r = rsgm_launch_vert3(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev);
+            } else {
+                if (whole > 0 &&
+                    (r = rsgm_launch_vert3_range(ctx, st, g.B, 0, whole, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev))) return r;
+                VPPX_HIP(hipEventRecord(ctx->ev_fork, st));
+                VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                ctx->stream = ctx->stream2;
+                r = launch_we();
+                ctx->stream = st;
+                if (r) return r;
+                VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+                r = rsgm_launch_vert3_range(ctx, st, g.B, whole, g.B - whole, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev);
+                VPPX_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+                we_launched = true;
+            }
             if (timed) {
                 VPPX_HIP(hipEventRecord(ctx->agg_ev[1][slot], st));
                 ctx->agg_calls++;
@@ -760,6 +785,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
 #endif
             if (we_first) {
                 if ((rc = launch_we())) return rc;
+                we_launched = true;
                 if ((rc = launch_vert(ctx->stream))) return rc;
             } else {
                 if ((rc = launch_vert(ctx->stream))) return rc;
@@ -772,7 +798,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                     ctx->have_agg_done = true;
                     ctx->agg_done_recorded = true;
                 }
-                if ((rc = launch_we())) return rc;
+                if (!we_launched && (rc = launch_we())) return rc;
             }
         } else if (which == 0) {
             VPPX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));

@@ -131,6 +131,7 @@ struct vppx_ctx {
         int we_line = 0;      // "we_line": W / E of the fused layout on the line-parallel kernel instead of sgm_we12_kernel
         int sum_gl8 = 0;      // "sum_gl8": 8 lanes per pixel in the fused sum / WTA kernel (D = 128 / 192)
         int sum_trap = 2;     // D = 256, fused layout: trapezoid ring with spare slots; "sum_trap1": without them; "sum_trap0": uniform ring, 32-pixel rounds
+        int we_next = 1;      // W/E next to an under-filled lock-step launch (rsgm_vert3_plan); "we_after": always behind it
         int sum_blocks = 0;   // (EXP=1 builds) "sum_blocks=N": forced number of blocks of the sum / WTA kernel
     } knobs;
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
@@ -296,6 +297,9 @@ bool rsgm_vert3_fits(const vppx_ctx *ctx, int B, int Wp, int D);
 int rsgm_vert3_frames_per_round(const vppx_ctx *ctx, int Wp, int D);
 bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
+void rsgm_vert3_plan(const vppx_ctx *ctx, int B, int Wp, int D, int *whole_frames, bool *rest_underfilled);
+int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int f0, int nB, int Hp, int Wp, int D, const u8 *gray,
+                            const u32 *cl, const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev);
 int rsgm_launch_void_if_lost(vppx_ctx *ctx, float *out, size_t n, const unsigned *err_dev, unsigned serial);
