@@ -134,7 +134,7 @@ int vppx_set_stream_legacy(vppx_ctx *ctx);
 /* Cross-call pipelining for streams of batches through vppx_occ_vpp_rsgm_dev / vppx_vpp_rsgm_dev: with `on`, the front
  * stage of a call (occlusion heuristic, VPP, pad + gray, census) runs on a second stream as soon as the PREVIOUS call's
  * aggregation is done, i.e. next to that call's sum / WTA and post kernels (calls that take the 8-path layout -- fewer than
- * 6 frames -- leave most of the GPU idle during their aggregation: there the next front stage starts as soon as the previous
+ * 3 frames -- leave most of the GPU idle during their aggregation: there the next front stage starts as soon as the previous
  * one has delivered its results, next to that aggregation; the gray / census images exist twice for this).  A call of more
  * frames than one batch quantum (vppx_batch_quantum) runs as consecutive parts of one quantum each, pipelined like separate
  * calls; results do not depend on the split.  Safe by construction:
@@ -349,7 +349,7 @@ int vppx_time_aggregate_frames(vppx_ctx *ctx);
 int vppx_time_aggregate_part(vppx_ctx *ctx, int iters, int part, float *ms_out);
 /* Aggregation layout of the last fused / rsgm call: 0 = all 8 paths in the line-parallel kernel, 3 = N/NW/NE and
  * S/SW/SE fused three at a time in the lock-step kernel + W and E line-parallel (register-window kernel for D = 128 / 192 /
- * 256) (default for D = 128 / 192 from 6 frames per call on; environment VPPX_VERT = 0 / 3 forces a layout), 1 = the round-1
+ * 256) (default for D = 128 / 192 from 3 frames per call on; environment VPPX_VERT = 0 / 3 forces a layout), 1 = the round-1
  * band-marching experiment
  * (VPPX_VERT = 1).  All layouts give identical results. */
 int vppx_uses_vert(vppx_ctx *ctx);

@@ -44,7 +44,7 @@ def test_two_ranks_sharing_the_device_equal_one_rank(tmp_path, B, H, W, D):
         want.append(eng.vpp_rsgm(left, right, hints, g_occ="occlusion_heuristic", seed=vdist.frame_seed(5 + step, 0),
                                  rsgm_kw=dict(dmax=D, subpixel=1)).clone())
     eng.synchronize()
-    assert eng.uses_vert() == (3 if n_total >= 6 and D in (128, 192) else 0)
+    assert eng.uses_vert() == (3 if n_total >= 3 and D in (128, 192) else 0)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_rank.py"), str(r), str(world), str(port),
                                str(B), str(H), str(W), str(D), out_path], env=env) for r in range(world)]
     for p in procs:

@@ -1,6 +1,6 @@
 """GPU parity of the optional execution variants (environment read at context creation, include/vppx.h "environment"):
 the aggregation layouts (VPPX_VERT: 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel; the default
-picks 3 from 6 frames per launch on), sub-stream splitting (VPPX_SUBSTREAMS) and every VPPX_VARIANT token: other
+picks 3 from 3 frames per launch on), sub-stream splitting (VPPX_SUBSTREAMS) and every VPPX_VARIANT token: other
 lanes-per-pixel layouts of the line-parallel kernel (gw4 / gw8 / gw16), W / E on the line-parallel kernel (we_line), the
 general sum / WTA decision code (sum_general), 8 lanes per pixel in the sum kernel (sum_gl8), the D = 256 ring layouts
 (sum_trap0 / sum_trap1) and the one-wave-per-chain maxDistance kernels (maxdist_lds / maxdist_global).  Each variant runs in

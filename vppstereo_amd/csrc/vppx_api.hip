@@ -514,9 +514,10 @@ static int check_rsgm_params(const VppxRsgmParams &p)
 // Would a call of this geometry take the fused layout (W/E line-parallel + the lock-step vertical kernel)?  use_vert: -1
 // (default) = pick by shape, 0 = eight line-parallel paths, 3 = fused whenever the shape allows it.  Probes the device on
 // the first question (block placement, residency).
-// frames per launch from which the fused layout wins (540x960x192, ms per frame 8-path / fused, round 4: 4 frames 0.44 / 0.46,
-// 6 frames 0.43 / 0.39, 8 frames 0.37 / 0.32)
-#define VPPX_FUSED_MIN_FRAMES 6
+// frames per launch from which the fused layout wins (540x960x192, ms per call 8-path / fused; round 5, with W/E next to the
+// under-filled lock-step launch: 2 frames 0.99 / 1.12, 3 frames 1.41 / 1.24, 4 frames 1.77 / 1.37, 5 frames 2.12 / 1.72; one
+// pair 0.56 / 1.03.  Round 4, W/E behind it: 4 frames 0.44 / 0.46 per frame, 6 frames 0.43 / 0.39: the threshold was 6)
+#define VPPX_FUSED_MIN_FRAMES 3
 static int fused_layout_wanted(vppx_ctx *ctx, const RsgmGeom &g, int maxp2, bool *out)
 {
     int rc;
