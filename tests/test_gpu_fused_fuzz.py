@@ -249,3 +249,29 @@ def test_pipelined_front_stage_at_d256_matches_unpipelined_and_oracle(env, B, H,
         lo, ro = oracle.vpp(b["left"][f], b["right"][f], b["hints"][f], g_occ=conf)
         assert np.array_equal(lo, got[2][2][f].cpu().numpy()) and np.array_equal(ro, got[2][3][f].cpu().numpy()), f
         assert np.array_equal(oracle.compute_rsgm(b["left"][f], lo, ro, dmax=D, subpixel=True), got[2][0][f].cpu().numpy()), f
+
+
+@pytest.mark.parametrize("B,H,W", [(8, 9, 5), (8, 12, 44), (9, 7, 64), (8, 10, 70), (6, 21, 130), (8, 6, 200), (3, 17, 333), (8, 5, 1030)])
+def test_trapezoid_ring_at_d256_every_width(engines, B, H, W):
+    """sum_wta_trap_kernel (D = 256, fused layout): padded widths below, at and above one 64-pixel round, rows that end inside a
+    round, blocks of one row and of many, 3 to 9 frames -- against the 8-path layout (uniform ring, 32-pixel rounds, another
+    kernel) bit for bit, frame 0 against the oracle; with and without sub-pixel refinement."""
+    import torch
+    fused, eight, wide = engines
+    b = synth.make_batch(B, H, W, 256, 0.06, seed=8800 + W)
+    args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(fused.device) for k in ("left", "right", "hints")]
+    for sub in (1, 0):
+        kw = dict(dmax=256, subpixel=sub, p1=7, p2min=13, gamma=40)
+        a = fused.vpp_rsgm(*args, seed=3, rsgm_kw=kw)
+        fused.synchronize()
+        assert fused.uses_vert() == 3
+        w = eight.vpp_rsgm(*args, seed=3, rsgm_kw=kw)
+        eight.synchronize()
+        assert eight.uses_vert() == 0
+        assert torch.equal(a, w), (B, H, W, sub)
+        c = wide.vpp_rsgm(*args, seed=3, rsgm_kw=kw)
+        wide.synchronize()
+        assert torch.equal(c, w), (B, H, W, sub)
+    oracle.init_rand(3)
+    lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
+    assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, dmax=256, subpixel=False, p1=7, p2min=13, gamma=40), a[0].cpu().numpy())

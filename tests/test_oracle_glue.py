@@ -78,3 +78,35 @@ def test_guided_dsi(G):  # rsgm.py:116-127
         got = oracle._guided_dsi(G[f"gdsi{i}_dsi"], G[f"gdsi{i}_hints"], G[f"gdsi{i}_valid"])
         assert got.dtype == np.uint16 and np.array_equal(got, G[f"gdsi{i}_out"]), i
         assert not np.array_equal(got, G[f"gdsi{i}_dsi"])
+
+
+def test_hint_range_equals_the_reference_wrappers_numpy_statements():
+    """vppstereo_amd.vpp_standalone.hint_range replaces `np.count_nonzero(gt) == 0` and `gt[gt > 0].min() / .max()`
+    (vpp_standalone.py:407,410-411) by two reductions and one pass over the bit patterns: same early-out, same (dmin, dmax) bit
+    for bit, same ValueError when the non-zero hints are all <= 0 or NaN -- over zeros, signed zeros, denormals, negatives,
+    infinities, NaNs and random maps."""
+    import pytest
+    from vppstereo_amd.vpp_standalone import hint_range
+
+    def ref(gt):
+        if np.count_nonzero(gt) == 0:
+            return (None, None)
+        pos = gt[gt > 0]
+        return float(pos.min()), float(pos.max())
+
+    rng = np.random.default_rng(5)
+    cases = [np.zeros((5, 7), np.float32), np.array([[0, -0.0], [0, 0]], np.float32), np.array([[0, 3.5], [1e-30, 0]], np.float32),
+             np.array([[0, -2.0], [0.5, 7]], np.float32), np.array([[np.inf, 2], [0, 0]], np.float32), np.array([[np.nan, 2], [0, 5]], np.float32),
+             np.array([[1e-45, 0], [0, 0]], np.float32), np.array([[-np.inf, 1.25]], np.float32), np.full((3, 3), 191.5, np.float32)]
+    for _ in range(60):
+        a = rng.normal(0, 10, (13, 17)).astype(np.float32)
+        a[rng.random(a.shape) < 0.7] = 0
+        cases.append(a)
+    for c in cases:
+        assert hint_range(c) == ref(c), c
+    for bad in (np.array([[0, -1.0]], np.float32), np.array([[np.nan, 0]], np.float32), np.array([[-np.inf, -0.0]], np.float32)):
+        with pytest.raises(ValueError):
+            ref(bad)
+        with pytest.raises(ValueError):
+            hint_range(bad)
+    assert hint_range(np.zeros((0, 4), np.float32)) == (None, None)
