@@ -374,7 +374,7 @@ int vppx_get_stage_ms(vppx_ctx *ctx, float *ms, int max_n);
 const char *vppx_stage_name(int i);
 
 /* ---- environment ------------------------------------------------------------------------------
- * Every variable the shipped library reads, all of them ONCE, in vppx_create (nothing else calls getenv; `make EXP=1`
+ * Every variable the shipped library reads, all of them ONCE, in vppx_create (nothing else calls getenv; `tools/build_exp.sh`
  * measurement builds add VPPX_V3_IGNORE_LOST and VPPX_EXP_*, tools/ only):
  *   VPPX_VERT           aggregation layout: -1 / unset = by shape, 0 = eight line-parallel paths, 3 = fused layout whenever the
  *                       shape allows it, 1 = the round-1 band-marching kernel (vppx_uses_vert)

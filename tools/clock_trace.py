@@ -1,4 +1,4 @@
-"""tools/clock_trace.py [B]: the shader clock over time while the bench loop runs (EXP=1 build).  One extra wave samples
+"""tools/clock_trace.py [B]: the shader clock over time while the bench loop runs (tools/build_exp.sh build: VPPX_LIB=tools/bin/libvppx_exp.so).  One extra wave samples
 s_memtime (shader cycles) against s_memrealtime (100 MHz) every 20 us while five pipelined steps run."""
 import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box, repo root, `make EXP=1` build): tools/exp_bench.sh <out.jsonl> "<ENV=..>" ["<ENV=..>" ...]
+# Usage (GPU box, repo root, `tools/build_exp.sh` build, VPPX_LIB=tools/bin/libvppx_exp.so): tools/exp_bench.sh <out.jsonl> "<ENV=..>" ["<ENV=..>" ...]
 # bench.py (headline loop only) once per environment; one summary line each.
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"

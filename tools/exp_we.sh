@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box, repo root, library built with `make EXP=1`): tools/exp_we.sh <outdir>
+# Usage (GPU box, repo root, library built with `tools/build_exp.sh`, VPPX_LIB=tools/bin/libvppx_exp.so): tools/exp_we.sh <outdir>
 # What precedes the W/E launch of a step, one configuration per process (tools/we_probe.py).
 out=${1:-gpurun_out/exp_we}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"

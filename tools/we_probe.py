@@ -1,6 +1,6 @@
 """tools/we_probe.py [B [steps]]: the bench loop (occlusion heuristic + VPP + rSGM, inputs resident, cross-step overlap on
 and off) with the in-step duration of BOTH aggregation launches (event pairs on the launch stream) next to their
-back-to-back re-launch figures.  The environment's VPPX_* knobs (experiment hooks need a `make EXP=1` build) are echoed."""
+back-to-back re-launch figures.  The environment's VPPX_* knobs (experiment hooks need a `tools/build_exp.sh` build, VPPX_LIB=tools/bin/libvppx_exp.so) are echoed."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -199,7 +199,7 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
         if (e && atoi(e) > 0) ctx->v3.timeout_ms = atoi(e);
         e = getenv("VPPX_V3_PPW");
         if (e && (atoi(e) == 8 || atoi(e) == 16)) ctx->v3.ppw = atoi(e);
-#ifdef VPPX_EXPERIMENT // measurement builds only (make EXP=1): the shipped library cannot be told to ignore a lost lock step
+#ifdef VPPX_EXPERIMENT // measurement builds only (tools/build_exp.sh): the shipped library cannot be told to ignore a lost lock step
         e = getenv("VPPX_V3_IGNORE_LOST");
         if (e && atoi(e) > 0) ctx->v3.ignore_lost = true;
 #endif
@@ -542,7 +542,7 @@ static int fused_layout_wanted(vppx_ctx *ctx, const RsgmGeom &g, int maxp2, bool
 }
 
 #ifdef VPPX_EXPERIMENT
-// Experiment hooks (never in the shipped build; `make EXP=1`): what runs right before the W/E launch of a step.
+// Experiment hooks (never in the shipped build; tools/build_exp.sh): what runs right before the W/E launch of a step.
 //   VPPX_EXP_PRE=1  read every census / gray byte the launch will read (warms L2 / MALL / TLB of those)
 //   VPPX_EXP_PRE=2  read one dword per 4 KB of the two volumes the launch writes (TLB of the store stream)
 //   VPPX_EXP_PRE=3  ~0.3 ms of dense VALU work on every CU (clock / power state)
@@ -774,7 +774,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
             // line.  The W/E launch pays 0.5-0.65 ms for going first (2.4-2.6 ms instead of 1.95 back to back;
             // tools/we_probe.py), the fused vertical kernel 0.2-0.3 ms: it goes first (round 4: bench step 9.66 -> 9.45 ms
             // on the same box).  Reading the images once in a launch of its own has the same effect (VPPX_EXP_PRE=1 of an
-            // EXP=1 build).  (Also tried in round 4, bit-exact, not kept: the vertical kernel adding W's and E's bytes to
+            // experiment build).  (Also tried in round 4, bit-exact, not kept: the vertical kernel adding W's and E's bytes to
             // its two sums -- 3 whole-line loads per lane and row, prefetched a row ahead -- so that the sum kernel reads
             // two volumes: sum / WTA 2.46 -> 2.09 ms, but the lock-step kernel 3.5 -> 4.55 ms whatever the loads'
             // distance, cache policy or target (in place or not): HBM-latency loads in its CUs' miss queues hold up the
@@ -790,7 +790,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 if ((rc = launch_vert(ctx->stream))) return rc;
             } else {
                 if ((rc = launch_vert(ctx->stream))) return rc;
-                // VPPX_PIPE_MID=1 (experiment, off): the NEXT call's front stage starts here, next to the W/E launch and the sum / WTA
+                // VPPX_VARIANT=pipe_mid (experiment builds; measured slower at D = 192 and at D = 256): the NEXT call's front stage starts here, next to the W/E launch and the sum / WTA
                 // kernel (it used to start after the whole aggregation).  The lock-step kernel is the one that suffers from
                 // neighbours and it is done; the images W/E still reads belong to this call's set of the two alternating
                 // sets (rsgm_core), which the next front stage does not touch.

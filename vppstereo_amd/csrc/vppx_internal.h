@@ -132,7 +132,7 @@ struct vppx_ctx {
         int sum_gl8 = 0;      // "sum_gl8": 8 lanes per pixel in the fused sum / WTA kernel (D = 128 / 192)
         int sum_trap = 2;     // D = 256, fused layout: trapezoid ring with spare slots; "sum_trap1": without them; "sum_trap0": uniform ring, 32-pixel rounds
         int we_next = 1;      // W/E next to an under-filled lock-step launch (rsgm_vert3_plan); "we_after": always behind it
-        int sum_blocks = 0;   // (EXP=1 builds) "sum_blocks=N": forced number of blocks of the sum / WTA kernel
+        int sum_blocks = 0;   // (experiment builds) "sum_blocks=N": forced number of blocks of the sum / WTA kernel
     } knobs;
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
     int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
@@ -145,7 +145,7 @@ struct vppx_ctx {
     bool have_agg_done = false;
     bool pipe_early = false;       // this pipelined call lets the next front stage start next to its aggregation (few frames per call)
     int pipe_parity = 0;           // which set of gray / census images the next pipelined call writes
-    bool pipe_mid = false;         // the next front stage starts behind the fused vertical kernel, next to W/E (VPPX_PIPE_MID)
+    bool pipe_mid = false;         // the next front stage starts behind the fused vertical kernel, next to W/E (VPPX_VARIANT=pipe_mid of an experiment build)
     bool agg_done_recorded = false; // ... and this call's aggregation has recorded ev_agg_done already
     const u8 *last_gl = nullptr;   // the images the last call aggregated from (timing helpers)
     const u32 *last_cl = nullptr, *last_cr = nullptr;
@@ -183,7 +183,7 @@ struct vppx_ctx {
         unsigned spin_limit = 0;   // polls per wait, 0 = unbounded (VPPX_V3_SPIN_LIMIT: tests force the give-up path with 1)
         unsigned serial = 0;       // serial of the last fused launch
         int last_ppw = 0;          // pixels per wave of the last fused launch (8: sgm_vert3_kernel, 16: sgm_vert4_kernel)
-        bool ignore_lost = false;  // VPPX_V3_IGNORE_LOST (EXP=1 builds only): measurement runs with forced give-ups (results void) carry on
+        bool ignore_lost = false;  // VPPX_V3_IGNORE_LOST (experiment builds only): measurement runs with forced give-ups (results void) carry on
     } v3;
     DevBuf ws[WS_NUM];
     std::string devname;
@@ -209,7 +209,7 @@ struct vppx_ctx {
     bool lut_valid = false;
     int lut_p2min = 0, lut_gamma = 0, lut_maxp2 = 0;
     float lut_alpha = 0.f;
-    // hipGraph replay of the fused call (VPPX_GRAPH=1 / vppx_set_graph_mode): the second identical call
+    // hipGraph replay of the fused call (vppx_set_graph_mode): the second identical call
     // (same shapes, parameters and pointers) is stream-captured, later ones launch the instantiated graph
     struct GraphKey {
         int B, H, W, C;
