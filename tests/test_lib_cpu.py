@@ -123,3 +123,29 @@ def test_get_seed_is_wall_clock_seconds():
     from vppstereo_amd import vpp_core_opt
     s = vpp_core_opt.get_seed()
     assert isinstance(s, float) and abs(s - time.time()) < 5.0
+
+
+def test_every_environment_variable_the_library_reads_is_documented_in_the_header():
+    """Hygiene guard: `getenv` appears only in vppx_create (one translation unit), every name it reads is listed in include/vppx.h's
+    environment section, and the shipped (non-experiment) build reads at most eight."""
+    import re
+    csrc = os.path.join(ROOT, "vppstereo_amd", "csrc")
+    header = open(os.path.join(ROOT, "include", "vppx.h")).read()
+    shipped, experiment = set(), set()
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        depth_exp = 0
+        for line in open(os.path.join(csrc, name)):
+            s = line.strip()
+            if s.startswith("#ifdef VPPX_EXPERIMENT"):
+                depth_exp += 1
+            elif s.startswith("#endif") and depth_exp:
+                depth_exp -= 1
+            code = line.split("//")[0]
+            for m in re.finditer(r'getenv\("(\w+)"\)', code):
+                assert name == "vppx_api.hip", (name, m.group(1))
+                (experiment if depth_exp else shipped).add(m.group(1))
+    assert shipped and len(shipped) <= 8, shipped
+    for v in shipped | experiment:
+        assert v in header, v
