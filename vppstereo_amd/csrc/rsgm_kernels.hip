@@ -2296,7 +2296,8 @@ void rsgm_vert3_plan(const vppx_ctx *ctx, int B, int Wp, int D, int *whole_frame
 // One launch of the fused vertical kernel over the frames [f0, f0 + nB) of a batch of B_total (the volume's pass stride);
 // first: the batch's first launch (new serial, records cleared).
 int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int f0, int nB, int Hp, int Wp, int D, const u8 *gray,
-                            const u32 *cl, const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev)
+                            const u32 *cl, const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev,
+                            bool next_to_we)
 {
     if (f0 == 0) {
         ++ctx->v3.serial; // one serial per aggregation, whatever the number of launches (void_if_lost_kernel)
@@ -2318,7 +2319,17 @@ int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int 
     a.gray = gray + fpix; a.cl = cl + fpix; a.cr = cr + fpix; a.p2lut = p2lut; a.sv = sv + fpix * D; a.xbuf = xbuf; a.err = err; a.err_dev = err_dev;
     a.B = nB; a.Hp = Hp; a.Wp = Wp;
     a.p1 = p1 > 231 ? 231 : p1; // exact for P1 >= P2max (see rsgm_launch_paths); keeps the small-value update in range
-    const bool wide = v3_wide(ctx, nB, Wp, D);
+    bool wide = v3_wide(ctx, nB, Wp, D);
+    if (!wide && next_to_we && Wp % 16 == 0 && ctx->v3.ppw == 0) {
+        // With W/E running next to it the launch's idle SIMDs are not idle: what counts is its own instruction count, and the
+        // 16-pixel kernel spends 13 % fewer -- from half a round on (below that its groups are alone on their XCDs and run at a
+        // lone wave's pace whichever kernel they are).  540x960x192, ms per call 8 / 16 pixels per wave: 8 frames 2.25 / 2.14,
+        // 9 frames 2.72 / 2.67, 10 frames 3.06 / 2.78, 4 frames 1.35 / 1.68; 375x1242x192 (3 groups per XCD and round), 8 frames:
+        // 2.32 / 2.35 -- hence only where a round holds at least 4 groups per XCD.
+        const int nbg16 = (Wp / 16 + 3) / 4;
+        const int resident = ctx->v3.cus_per_xcd * ctx->v3.blocks_per_cu16[v3_dk(D)] / (nbg16 > 0 ? nbg16 : 1);
+        wide = resident >= 4 && 2 * nB >= ctx->v3.nxcd * ((resident + 1) / 2);
+    }
     if (f0 == 0) ctx->v3.last_ppw = wide ? 16 : 8;
     a.nwv = wide ? Wp / 16 : Wp / 8;
     a.nbg = (a.nwv + 3) / 4;
@@ -2342,7 +2353,7 @@ int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int 
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev)
 {
-    return rsgm_launch_vert3_range(ctx, stream, B, 0, B, Hp, Wp, D, gray, cl, cr, p2lut, p1, sv, xbuf, err, err_dev);
+    return rsgm_launch_vert3_range(ctx, stream, B, 0, B, Hp, Wp, D, gray, cl, cr, p2lut, p1, sv, xbuf, err, err_dev, false);
 }
 
 // ---------------------------------------------------------------------------------------

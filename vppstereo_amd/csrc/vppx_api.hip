@@ -749,7 +749,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 r = rsgm_launch_vert3(ctx, st, g.B, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev);
             } else {
                 if (whole > 0 &&
-                    (r = rsgm_launch_vert3_range(ctx, st, g.B, 0, whole, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev))) return r;
+                    (r = rsgm_launch_vert3_range(ctx, st, g.B, 0, whole, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev, false))) return r;
                 VPPX_HIP(hipEventRecord(ctx->ev_fork, st));
                 VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
                 ctx->stream = ctx->stream2;
@@ -757,7 +757,7 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 ctx->stream = st;
                 if (r) return r;
                 VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
-                r = rsgm_launch_vert3_range(ctx, st, g.B, whole, g.B - whole, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev);
+                r = rsgm_launch_vert3_range(ctx, st, g.B, whole, g.B - whole, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev, true);
                 VPPX_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
                 we_launched = true;
             }

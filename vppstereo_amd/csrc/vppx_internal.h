@@ -299,7 +299,8 @@ bool rsgm_vert3_wide(const vppx_ctx *ctx, int B, int Wp, int D);
 size_t rsgm_vert3_xbuf_bytes(int B, int Wp, int D);
 void rsgm_vert3_plan(const vppx_ctx *ctx, int B, int Wp, int D, int *whole_frames, bool *rest_underfilled);
 int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int f0, int nB, int Hp, int Wp, int D, const u8 *gray,
-                            const u32 *cl, const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev);
+                            const u32 *cl, const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev,
+                            bool next_to_we);
 int rsgm_launch_vert3(vppx_ctx *ctx, hipStream_t stream, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl,
                       const u32 *cr, const u16 *p2lut, int p1, u8 *sv, u32 *xbuf, unsigned *err, unsigned *err_dev);
 int rsgm_launch_void_if_lost(vppx_ctx *ctx, float *out, size_t n, const unsigned *err_dev, unsigned serial);
