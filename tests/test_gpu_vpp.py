@@ -360,3 +360,9 @@ def test_run_frame_equals_the_three_drop_in_calls(maskocc, method):
             assert np.array_equal(conf, want[i][3])
     d2 = pipeline.run_frame(fr["left"], fr["right"], np.zeros_like(fr["hints"]), maskocc=maskocc, rsgm_kw=dict(dmax=D))   # no hints at all
     assert np.array_equal(d2, rsgm.compute_rsgm(fr["left"], fr["left"], fr["right"], dmax=D))
+    # no hints and use_distance_patch: vpp() returns the untouched pair before dmin / dmax are looked at (vpp_standalone.py:407)
+    lc0, rc0 = vpp_standalone.vpp(fr["left"], fr["right"], np.zeros_like(fr["hints"]), use_distance_patch=True)
+    assert np.array_equal(lc0, fr["left"]) and np.array_equal(rc0, fr["right"])
+    d3 = pipeline.run_frame(fr["left"], fr["right"], np.zeros_like(fr["hints"]), maskocc=maskocc, vpp_kw=dict(use_distance_patch=True),
+                            rsgm_kw=dict(dmax=D))
+    assert np.array_equal(d3, d2)

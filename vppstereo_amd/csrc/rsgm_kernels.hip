@@ -2330,6 +2330,17 @@ int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int 
         const int resident = ctx->v3.cus_per_xcd * ctx->v3.blocks_per_cu16[v3_dk(D)] / (nbg16 > 0 ? nbg16 : 1);
         wide = resident >= 4 && 2 * nB >= ctx->v3.nxcd * ((resident + 1) / 2);
     }
+    {
+        // residency of the kernel actually chosen for THIS launch (rsgm_vert3_fits priced the whole batch's choice): a group
+        // that cannot be co-resident with room to spare takes the other kernel when that one fits
+        const int k = v3_dk(D);
+        auto fits = [&](bool w) {
+            const int nbg = ((w ? Wp / 16 : Wp / 8) + 3) / 4;
+            const int bpc = w ? ctx->v3.blocks_per_cu16[k] : ctx->v3.blocks_per_cu[k];
+            return (!w || Wp % 16 == 0) && nbg <= ctx->v3.cus_per_xcd * bpc * 3 / 4;
+        };
+        if (!fits(wide) && fits(!wide)) wide = !wide;
+    }
     if (f0 == 0) ctx->v3.last_ppw = wide ? 16 : 8;
     a.nwv = wide ? Wp / 16 : Wp / 8;
     a.nbg = (a.nwv + 3) / 4;

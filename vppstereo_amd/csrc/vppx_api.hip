@@ -758,8 +758,14 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 if (r) return r;
                 VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
                 r = rsgm_launch_vert3_range(ctx, st, g.B, whole, g.B - whole, g.Hp, g.Wp, g.D, gl, cl, cr, lut_d, p.p1, sv, (u32 *)gst, ctx->vert3_err, err_dev, true);
+                // the pair closes behind the last lock-step launch, BEFORE the join: it must not contain W/E's tail
+                if (timed) {
+                    VPPX_HIP(hipEventRecord(ctx->agg_ev[1][slot], st));
+                    ctx->agg_calls++;
+                }
                 VPPX_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
                 we_launched = true;
+                return r;
             }
             if (timed) {
                 VPPX_HIP(hipEventRecord(ctx->agg_ev[1][slot], st));
@@ -1008,7 +1014,9 @@ static int rsgm_core(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeom &g, 
     if (rc < 0) return rc;
     if (rc == 0) {
         stage_mark(ctx, ST_SUM_WTA);
+        ctx->last_sum_nvol = nvol; ctx->last_sum_D = g.D; ctx->last_sum_B = g.B;
     } else {
+        ctx->last_sum_nvol = 0;
         u16 *S;
         if ((rc = ws_get(ctx, WS_S, ncell, &S))) return rc;
         if ((rc = rsgm_launch_sum_wta(ctx, g.B, g.Hp, g.Wp, g.D, vols[0], elem_bytes, nullptr, S, dl0, fu, 1))) return rc;
@@ -1291,7 +1299,10 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
         if (r_user) ctx->pipe_copy[ctx->n_pipe_copy++] = {r_user, r_vpp, nb, false};
     }
     {   // what the front-stage kernels may use of a CU's LDS: next to the previous part's sum / WTA kernel when pipelined
-        const size_t sum_lds = rsgm_sum_lds_bytes(ctx, rp->dmax, B >= VPPX_FUSED_MIN_FRAMES ? 4 : 8), cu_lds = 160 * 1024; // (the previous part has this part's shape)
+        // (the previous part has this part's shape: its real layout when it ran with this D and batch, else the threshold's guess)
+        const int nvol_prev = (ctx->last_sum_nvol && ctx->last_sum_D == rp->dmax && ctx->last_sum_B == B) ? ctx->last_sum_nvol
+                                                                                                          : (B >= VPPX_FUSED_MIN_FRAMES ? 4 : 8);
+        const size_t sum_lds = rsgm_sum_lds_bytes(ctx, rp->dmax, nvol_prev), cu_lds = 160 * 1024;
         const size_t left_over = cu_lds > sum_lds + 512 ? cu_lds - sum_lds - 512 : 2048;
         // (less than 6 KB left -- D = 256 on the trapezoid ring with spare slots, whose 4 x 125 VGPRs per SIMD leave no registers
         // either: nothing of the front stage can run NEXT to that kernel, so its kernels keep their efficient shapes and run in its tail)
@@ -1403,7 +1414,9 @@ extern "C" int vppx_occ_vpp_rsgm_host(vppx_ctx *ctx, const VppxOccParams *op, co
         if (dlv && (rc = download(ctx, l_vpp_out, dlv, nb))) return rc;
         if (drv && (rc = download(ctx, r_vpp_out, drv, nb))) return rc;
         std::vector<unsigned long long> tot;
-        if (draws_out && vp->method == VPPX_METHOD_RND && ctx->ws[WS_FRAME_TOT].p && ctx->last_parts == 1) {
+        // the totals of THIS context's single part only: parts overwrite each other's, sub-stream children keep their own
+        if (draws_out && vp->method == VPPX_METHOD_RND && ctx->ws[WS_FRAME_TOT].p && ctx->last_parts == 1 &&
+            ctx->ws[WS_FRAME_TOT].cap >= (size_t)B * 16) {
             tot.resize((size_t)B * 2);
             VPPX_HIP(hipMemcpyAsync(tot.data(), ctx->ws[WS_FRAME_TOT].p, tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         }
@@ -1614,6 +1627,7 @@ static int vpp_rsgm_entry(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
     }
     // timing helpers look at the last geometry of the first child
     ctx->have_last = false;
+    ctx->last_parts = 0; // the children's arenas hold the per-frame draw totals, not this context's (vppx_occ_vpp_rsgm_host reports 0)
     return 0;
 }
 

@@ -137,6 +137,8 @@ struct vppx_ctx {
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
     int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
     int last_parts = 1;            // parts the last fused call ran as (vppx_last_call_parts)
+    int last_sum_nvol = 0;         // volumes the last fused sum / WTA launch added (4: fused layout, 8: eight paths) and its
+    int last_sum_D = 0, last_sum_B = 0; // shape: what a pipelined front stage has to fit next to (vpp_rsgm_one)
     // cross-call pipelining (vppx_set_pipeline): the front stage of a fused call (occlusion heuristic, VPP, pad + gray,
     // census) runs on stream_front, after the PREVIOUS call's aggregation, i.e. under that call's sum / WTA and post kernels
     bool pipeline = false;

@@ -31,7 +31,8 @@ def run_frame(left, right, hints, maskocc=False, g_occ=None, occ_kw=None, vpp_kw
     h, w = gt.shape
     ch = 1 if left.ndim == 2 else left.shape[2]
     dmin, dmax = hint_range(gt)
-    if dmin is None:
+    no_hints = dmin is None
+    if no_hints:
         dmin, dmax = 0.0, 0.0     # no hints: the scan leaves the pair as it is (vpp_standalone.py:407)
     p = _lib.vpp_params(method=1 if method == "maxDistance" else 0, wsize=int(vk.pop("wsize", 3)), wsize_agg_x=int(vk.pop("wsizeAgg_x", 64)),
                         wsize_agg_y=int(vk.pop("wsizeAgg_y", 3)), direction=1 if vk.pop("left2right", True) else 0,
@@ -43,6 +44,8 @@ def run_frame(left, right, hints, maskocc=False, g_occ=None, occ_kw=None, vpp_kw
                         bilateral_th=float(vk.pop("bilateral_th", .001)))
     if vk:
         raise TypeError(f"unknown vpp keyword(s): {sorted(vk)}")
+    if no_hints:
+        p.use_distance_patch = 0  # vpp() returns the untouched pair before dmin / dmax are looked at (vpp_standalone.py:407)
     if p.use_distance_patch and not dmax > dmin:
         raise ZeroDivisionError("use_distance_patch needs two distinct hint values (vpp_standalone.py:8 divides by dmax-dmin)")
     rk = dict(rsgm_kw or {})
