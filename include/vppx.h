@@ -271,6 +271,44 @@ int vppx_occ_vpp_rsgm_host(vppx_ctx *ctx, const VppxOccParams *op, const VppxVpp
                            int W, int C, const uint8_t *left, const uint8_t *right, const float *g, const uint8_t *g_occ,
                            uint8_t *conf_out, uint8_t *l_vpp_out, uint8_t *r_vpp_out, float *disp_out, uint64_t *draws_out);
 
+/* ---- frame stream: the hot path for callers that hold one host frame at a time ---------------------------------------
+ * test.py:291-311 iterates a DataLoader with batch size 1 and runs :154-225 per frame on numpy arrays; the kernels want
+ * batches of one lock-step round, resident.  A frame stream takes (left, right, hints[, g_occ]) host arrays one frame at a
+ * time and returns the disparities (and, by flags, mask and patterned pair) one frame at a time IN INPUT ORDER.  Inside,
+ * every frame is copied once, by `copy_threads` threads, into a page-locked ring of `depth` batches; a full batch (`batch`
+ * frames, vppx_batch_quantum is a good value) is uploaded on a copy stream under the previous batch's kernels, runs through
+ * vppx_occ_vpp_rsgm_dev (op != NULL: the mask of test.py:154 on the way) or vppx_vpp_rsgm_dev with cross-call pipelining,
+ * and comes down on a third stream.  Frame f (counted from the stream's creation) draws from srand(vp->seed + f): results
+ * equal one-frame calls with that seed whatever the batch size and wherever a flush falls.  The context must launch on
+ * its own stream (the default of vppx_create) and must not be used for other calls while the stream exists.
+ * A lost lock step (vppx_status) is handled inside: pop verifies each batch after its download and re-runs what was in
+ * flight from the device inputs it still holds (vppx_fstream_counts reports how often).  Not thread-safe: one producer /
+ * consumer thread (the calls release nothing to other threads but do not hold Python's GIL).
+ * flags: VPPX_FS_PATTERNS pop can return the patterned pair; VPPX_FS_MASK (with op) the mask; VPPX_FS_GOCC every push brings
+ * a caller's mask (op must be NULL).  copy_threads < 0: chosen from the host's core count.
+ * use_distance_patch is refused (VPPX_E_UNSUPPORTED): vpp() takes dmin / dmax from each frame's hints. */
+#define VPPX_FS_PATTERNS 1
+#define VPPX_FS_MASK 2
+#define VPPX_FS_GOCC 4
+typedef struct vppx_fstream vppx_fstream;
+int vppx_fstream_create(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppParams *vp, const VppxRsgmParams *rp, int batch,
+                        int depth, int H, int W, int C, int flags, int copy_threads, vppx_fstream **out);
+void vppx_fstream_destroy(vppx_fstream *fs);
+/* One frame in (host arrays of the stream's H x W x C).  Returns when the frame has been copied: the arrays may be
+ * reused at once.  The frame that completes a batch also queues the batch's upload, kernels and download (no waiting).
+ * Fails with VPPX_E_INVALID_ARG when `depth` whole batches are waiting to be popped. */
+int vppx_fstream_push(vppx_fstream *fs, const uint8_t *left, const uint8_t *right, const float *hints, const uint8_t *g_occ);
+/* Submit the frames pushed so far as a (smaller) batch: end of the sequence, or a latency bound. */
+int vppx_fstream_flush(vppx_fstream *fs);
+/* The next frame's results, in input order: *got = 1 and the arrays filled (NULL = not wanted; draws_out = rand() draws the
+ * frame consumed, 0 for maxDistance), waiting for its batch when that is still running; *got = 0 when nothing submitted is
+ * outstanding (frames of a batch still being filled need vppx_fstream_flush). */
+int vppx_fstream_pop(vppx_fstream *fs, float *disp_out, uint8_t *l_vpp_out, uint8_t *r_vpp_out, uint8_t *conf_out,
+                     uint64_t *draws_out, int *got);
+/* Frames pushed since creation, frames of the batch being filled, frames submitted and not yet popped, batches re-run
+ * after a lost lock step (any pointer may be NULL). */
+int vppx_fstream_counts(vppx_fstream *fs, int64_t *pushed, int64_t *filling, int64_t *unpopped, int64_t *reruns);
+
 /* ---- hand-off to the deep front-ends (test.py:179-200) -------------------------------------- */
 /* uint8 [B,H,W,C] (device) -> [B,C,Hq,Wq] float32 (dst_is_bf16 = 0) or bfloat16 (1) in [0,1]
  * (value/255. as the reference computes it), replicate-padded up to multiples of

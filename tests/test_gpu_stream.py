@@ -1,0 +1,163 @@
+"""GPU parity of the host-side streaming adapter (vppstereo_amd.pipeline.FrameStream over the C-ABI's vppx_fstream_*): a
+stream of numpy frames pushed one at a time equals one `run_frame` call per frame -- test.py:291-311 then :154-225 -- bit for
+bit: mask, patterned pair, disparities and the position of the frame's random stream afterwards."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(n, H, W, D, p, seed, gray=False):
+    out = []
+    for f in range(n):
+        fr = synth.make_frame(H, W, D, p, seed=seed + f)
+        l, r = (fr["left"][..., 1].copy(), fr["right"][..., 1].copy()) if gray else (fr["left"], fr["right"])
+        out.append((l, r, fr["hints"]))
+    return out
+
+
+def _one_by_one(frames, seed, maskocc, vpp_kw, rsgm_kw, g_occ=None):
+    """init_rand(seed + f); run_frame(frame f) -- and where the shared libc-like stream stands afterwards."""
+    from vppstereo_amd import _lib, pipeline, vpp_standalone
+    want = []
+    for f, (l, r, h) in enumerate(frames):
+        vpp_standalone.init_rand(seed + f)
+        d, lc, rc, conf = pipeline.run_frame(l, r, h, maskocc=maskocc, g_occ=None if g_occ is None else g_occ[f], vpp_kw=vpp_kw,
+                                             rsgm_kw=rsgm_kw, return_patterns=True)
+        s, c = C.c_uint32(), C.c_uint64()
+        _lib.check(_lib.load().vppx_rand_state(_lib.default_context().handle, C.byref(s), C.byref(c)))
+        want.append((d, lc, rc, conf, int(c.value)))
+    return want
+
+
+@pytest.mark.parametrize("maskocc", [True, False])
+def test_stream_of_37_frames_equals_37_run_frame_calls(maskocc):
+    """37 frames, batches of 16 (16 + 16 + a flushed 5): every result in input order, equal to the frame's own one-frame
+    call with srand(seed + f), including the number of rand() draws it consumed."""
+    from vppstereo_amd.pipeline import FrameStream
+    H, W, D, seed = 60, 150, 64, 11
+    frames = _frames(37, H, W, D, 0.05, 100)
+    kw = dict(wsize=5, blending=0.3, c_occ=0.2)
+    want = _one_by_one(frames, seed, maskocc, kw, dict(dmax=D, p1=9))
+    got, draws = [], []
+    with FrameStream(H, W, 3, batch=16, depth=2, seed=seed, maskocc=maskocc, vpp_kw=kw, rsgm_kw=dict(dmax=D, p1=9), return_patterns=True) as fs:
+        for r in fs.run(iter(frames)):
+            got.append(r)
+            draws.append(fs.last_draws)
+        assert fs.counts()[0] == 37 and fs.counts()[2] == 0 and fs.pending == 0
+    assert len(got) == 37
+    for f in range(37):
+        d, lc, rc, conf = got[f]
+        assert np.array_equal(d, want[f][0]), f
+        assert np.array_equal(lc, want[f][1]) and np.array_equal(rc, want[f][2]), f
+        if maskocc:
+            assert np.array_equal(conf, want[f][3]), f
+        else:
+            assert conf is None
+        assert draws[f] == want[f][4] and draws[f] > 0, f
+
+
+def test_stream_against_the_oracle_with_callers_masks_gray_frames_and_odd_batches():
+    """Gray frames, a caller's mask per push, batch 5, depth 3, push / pop by hand with a flush in the middle: the results do
+    not depend on where batch boundaries fall, and equal the CPU oracle."""
+    from vppstereo_amd.pipeline import FrameStream
+    H, W, D, seed = 48, 112, 64, 5
+    frames = _frames(13, H, W, D, 0.06, 300, gray=True)
+    rng = np.random.default_rng(3)
+    masks = [(rng.random((H, W)) < 0.3).astype(np.uint8) for _ in frames]
+    got = []
+    with FrameStream(H, W, 1, batch=5, depth=3, seed=seed, with_g_occ=True, vpp_kw=dict(c_occ=0.1), rsgm_kw=dict(dmax=D), return_patterns=True) as fs:
+        for f, (l, r, h) in enumerate(frames):
+            fs.push(l, r, h, masks[f])
+            if f == 6:
+                fs.flush()              # 5 + 2 | 5 + 1
+                assert fs.pending == 7
+                for _ in range(3):
+                    got.append(fs.pop())
+        fs.flush()
+        while True:
+            r = fs.pop()
+            if r is None:
+                break
+            got.append(r)
+        assert fs.pop() is None
+    assert len(got) == 13
+    for f, (l, r, h) in enumerate(frames):
+        oracle.init_rand(seed + f)
+        lo, ro = oracle.vpp(l[..., None], r[..., None], h, g_occ=masks[f], c_occ=0.1)
+        assert np.array_equal(got[f][1], lo[..., 0]) and np.array_equal(got[f][2], ro[..., 0]), f
+        assert np.array_equal(got[f][0], oracle.compute_rsgm(l[..., None], lo, ro, dmax=D)), f
+
+
+def test_stream_results_do_not_depend_on_batch_size_or_copy_threads():
+    from vppstereo_amd.pipeline import FrameStream, run_stream
+    H, W, D = 40, 96, 192
+    frames = _frames(19, H, W, D, 0.04, 500)
+    base = list(run_stream(iter(frames), batch=19, seed=3, maskocc=True, rsgm_kw=dict(dmax=D), copy_threads=1))
+    for batch, depth, thr in ((1, 2, 1), (3, 2, 4), (8, 4, -1)):
+        out = list(run_stream(iter(frames), batch=batch, depth=depth, seed=3, maskocc=True, rsgm_kw=dict(dmax=D), copy_threads=thr))
+        assert len(out) == len(base)
+        for a, b in zip(out, base):
+            assert np.array_equal(a, b), (batch, depth, thr)
+    with FrameStream(H, W, batch=None, rsgm_kw=dict(dmax=D)) as fs:      # the default batch is a whole lock-step round (or 16)
+        assert fs.batch >= 1
+
+
+def test_stream_refuses_what_it_cannot_do_and_reports_a_full_ring():
+    from vppstereo_amd import _lib
+    from vppstereo_amd.pipeline import FrameStream
+    with pytest.raises(Exception, match="use_distance_patch"):
+        FrameStream(32, 64, vpp_kw=dict(use_distance_patch=True))
+    with pytest.raises(ValueError):
+        FrameStream(32, 64, maskocc=True, with_g_occ=True)
+    with pytest.raises(TypeError):
+        FrameStream(32, 64, vpp_kw=dict(blendin=0.2))
+    fr = _frames(1, 32, 64, 64, 0.05, 1)[0]
+    with FrameStream(32, 64, batch=2, depth=2, rsgm_kw=dict(dmax=64)) as fs:
+        with pytest.raises(ValueError, match="shape"):
+            fs.push(fr[0][:-1], fr[1], fr[2])
+        with pytest.raises(ValueError, match="with_g_occ"):
+            fs.push(*fr, np.zeros((32, 64), np.uint8))
+        # the C-ABI itself refuses a push when `depth` whole batches wait to be popped (the Python class pops early instead)
+        lib = _lib.load()
+        for _ in range(4):
+            _lib.check(lib.vppx_fstream_push(fs._h, fr[0].ctypes.data, fr[1].ctypes.data, fr[2].ctypes.data, None))
+        rc = lib.vppx_fstream_push(fs._h, fr[0].ctypes.data, fr[1].ctypes.data, fr[2].ctypes.data, None)
+        assert rc == -1 and b"pop results first" in lib.vppx_last_error()
+        d = np.empty((32, 64), np.float32)
+        got = C.c_int(0)
+        for _ in range(4):
+            _lib.check(lib.vppx_fstream_pop(fs._h, d.ctypes.data, None, None, None, None, C.byref(got)))
+            assert got.value == 1
+        _lib.check(lib.vppx_fstream_pop(fs._h, d.ctypes.data, None, None, None, None, C.byref(got)))
+        assert got.value == 0
+
+
+def test_stream_reruns_batches_after_a_lost_lock_step():
+    """VPPX_V3_SPIN_LIMIT=1 makes the fused aggregation give up at the first neighbour record that is not there yet: the stream
+    notices at the pop, re-runs what was in flight on the line-parallel layout, and hands out the right disparities."""
+    from vppstereo_amd.pipeline import FrameStream
+    H, W, D = 40, 96, 192
+    frames = _frames(20, H, W, D, 0.04, 700)
+    with FrameStream(H, W, batch=8, seed=9, rsgm_kw=dict(dmax=D)) as ref:
+        want = list(ref.run(iter(frames)))
+    old = {k: os.environ.get(k) for k in ("VPPX_VERT", "VPPX_V3_SPIN_LIMIT")}
+    os.environ["VPPX_VERT"], os.environ["VPPX_V3_SPIN_LIMIT"] = "3", "1"
+    try:
+        fs = FrameStream(H, W, batch=8, seed=9, rsgm_kw=dict(dmax=D))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    with fs:
+        got = list(fs.run(iter(frames)))
+        assert fs.counts()[3] >= 1                      # at least one batch was run again
+        assert fs._ctx.lockstep_failures >= 1
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b) and not np.isnan(a).any()

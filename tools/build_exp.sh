@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/bin/exp_obj
 src=vppstereo_amd/csrc
-for f in vppx_api rsgm_kernels vpp_kernels handoff_kernels png_kernels; do
+for f in vppx_api vppx_fstream rsgm_kernels vpp_kernels handoff_kernels png_kernels; do
     if [ ! -f tools/bin/exp_obj/$f.o ] || [ $src/$f.hip -nt tools/bin/exp_obj/$f.o ] || [ $src/vppx_internal.h -nt tools/bin/exp_obj/$f.o ] || [ include/vppx.h -nt tools/bin/exp_obj/$f.o ]; then
         /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DVPPX_EXPERIMENT -Wno-unused-function -Wno-unused-variable -c $src/$f.hip -o tools/bin/exp_obj/$f.o &
     fi

@@ -29,7 +29,9 @@ EXPORTS = [
     "vppx_match_wta_right", "vppx_subpixel_refine", "vppx_median3x3", "vppx_rsgm_host", "vppx_rsgm_dev",
     "vppx_vpp_rsgm_dev", "vppx_rsgm_post_dev", "vppx_occ_vpp_rsgm_dev", "vppx_occ_vpp_rsgm_host", "vppx_inputs_ready_event", "vppx_u8_to_nchw_dev", "vppx_psmnet_cost_volume_dev", "vppx_raft_corr_modulate_dev", "vppx_kitti_disp_decode_dev", "vppx_png_decode_dev", "vppx_pfm_decode_dev", "vppx_occlusion_heuristic_host", "vppx_occlusion_heuristic_dev", "vppx_occlusion_heuristic_full_host", "vppx_occlusion_heuristic_full_dev", "vppx_set_graph_mode", "vppx_graph_replays", "vppx_time_aggregate", "vppx_agg_kernel_ms", "vppx_we_kernel_ms", "vppx_time_aggregate_frames", "vppx_time_aggregate_part", "vppx_uses_vert", "vppx_last_call_parts", "vppx_fused_pixels_per_wave", "vppx_batch_quantum",
     "vppx_enable_stage_timing", "vppx_get_stage_ms", "vppx_stage_name",
+    "vppx_fstream_create", "vppx_fstream_destroy", "vppx_fstream_push", "vppx_fstream_flush", "vppx_fstream_pop", "vppx_fstream_counts",
 ]
+FS_PATTERNS, FS_MASK, FS_GOCC = 1, 2, 4
 
 
 class VppxVppParams(C.Structure):
@@ -162,6 +164,14 @@ def load():
         lib.vppx_batch_quantum.argtypes = [vp, i, i, i]
         lib.vppx_enable_stage_timing.argtypes = [vp, i]
         lib.vppx_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i]
+        lib.vppx_fstream_create.argtypes = [vp, po, pv, pr, i, i, i, i, i, i, i, C.POINTER(vp)]
+        lib.vppx_fstream_destroy.argtypes = [vp]
+        lib.vppx_fstream_destroy.restype = None
+        lib.vppx_fstream_push.argtypes = [vp, vp, vp, vp, vp]
+        lib.vppx_fstream_flush.argtypes = [vp]
+        lib.vppx_fstream_pop.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        p64 = C.POINTER(C.c_int64)
+        lib.vppx_fstream_counts.argtypes = [vp, p64, p64, p64, p64]
         _lib = lib
         return lib
 

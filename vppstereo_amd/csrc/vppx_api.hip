@@ -24,21 +24,6 @@ void vppx_set_error(const char *fmt, ...)
 extern "C" const char *vppx_last_error(void) { return g_err; }
 extern "C" int vppx_version(void) { return VPPX_VERSION; }
 
-// Every entry point runs with the context's device current and puts the caller's device back on return
-// (a torch process may hold contexts on several GPUs; the library must not change its current device).
-struct DevGuard {
-    int prev = -1;
-    bool changed = false;
-    explicit DevGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) changed = (hipSetDevice(dev) == hipSuccess);
-    }
-    ~DevGuard()
-    {
-        if (changed && prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 #define VPPX_ENTER(ctx)                                                                                              \
     if (!(ctx)) { vppx_set_error("context is NULL (vppx_create failed? there is no CPU fallback)"); return VPPX_E_NO_DEVICE; } \
     DevGuard dev_guard_((ctx)->device);                                                                                  \
@@ -331,6 +316,8 @@ static int lockstep_check(vppx_ctx *ctx)
                    serial, ctx->v3.timeout_ms, ctx->v3.spin_limit ? " / VPPX_V3_SPIN_LIMIT polls" : "", ctx->v3.serial, ctx->vert3_rest);
     return VPPX_E_HIP;
 }
+
+int vppx_lockstep_check_internal(vppx_ctx *ctx) { return lockstep_check(ctx); } // (vppx_fstream.hip)
 
 extern "C" int vppx_synchronize(vppx_ctx *ctx)
 {
@@ -1331,6 +1318,8 @@ static int vpp_rsgm_one(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppPar
         filled_g = fg;
     }
     if ((rc = vpp_launch(ctx, *vp, vg, l_vpp, r_vpp, g, g_occ, filled_g, nullptr, nullptr, right))) return rc;
+    if (ctx->draws_dst && vp->method == VPPX_METHOD_RND) // a frame stream keeps every frame's draw count (library-owned destination)
+        VPPX_HIP(hipMemcpy2DAsync(ctx->draws_dst, 8, ctx->ws[WS_FRAME_TOT].p, 16, 8, (size_t)B, hipMemcpyDeviceToDevice, ctx->stream));
     RsgmGeom rg;
     make_geom(B, H, W, C, rp->dmax, rg);
     return rsgm_core(ctx, *rp, rg, left, l_vpp, r_vpp, disp_out);
@@ -1494,12 +1483,15 @@ static int vpp_rsgm_parts(vppx_ctx *ctx, const VppxOccParams *op, const VppxVppP
         }
     }
     int lo = 0;
+    unsigned long long *const draws_base = ctx->draws_dst;
+    struct DrawsRestore { vppx_ctx *c; unsigned long long *p; ~DrawsRestore() { c->draws_dst = p; } } draws_restore{ctx, draws_base};
     for (size_t pi = 0; pi < plan.size(); pi++) {
         const int nb = plan[pi];
         VppxVppParams v2 = *vp;
         v2.seed = vp->seed + (uint32_t)lo; // frame f keeps srand(seed + f) whatever the split
         ctx->inputs_ev = inputs_ev;
         ctx->stage_append = lo > 0;
+        ctx->draws_dst = draws_base ? draws_base + lo : nullptr;
         rc = vpp_rsgm_one(ctx, op, &v2, rp, nb, H, W, C, left + (size_t)lo * fpx * C, right + (size_t)lo * fpx * C,
                           g + (size_t)lo * fpx, g_occ ? g_occ + (size_t)lo * fpx : nullptr,
                           conf_out ? conf_out + (size_t)lo * fpx : nullptr,

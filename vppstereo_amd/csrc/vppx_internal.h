@@ -29,6 +29,22 @@ void vppx_set_error(const char *fmt, ...);
 
 #define VPPX_CHECK_LAUNCH() VPPX_HIP(hipGetLastError())
 
+// Every entry point runs with the context's device current and puts the caller's device back on return
+// (a torch process may hold contexts on several GPUs; the library must not change its current device).
+struct DevGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DevGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) changed = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DevGuard()
+    {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // workspace arena: named, grow-only device buffers owned by the context.  Everything the
 // pipeline needs between kernels lives in HBM for the lifetime of the context (288 GB:
@@ -137,6 +153,7 @@ struct vppx_ctx {
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
     int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
     int last_parts = 1;            // parts the last fused call ran as (vppx_last_call_parts)
+    unsigned long long *draws_dst = nullptr; // device [B]: where the fused call leaves every frame's draw count (set per call by a frame stream)
     int last_sum_nvol = 0;         // volumes the last fused sum / WTA launch added (4: fused layout, 8: eight paths) and its
     int last_sum_D = 0, last_sum_B = 0; // shape: what a pipelined front stage has to fit next to (vpp_rsgm_one)
     // cross-call pipelining (vppx_set_pipeline): the front stage of a fused call (occlusion heuristic, VPP, pad + gray,
