@@ -166,15 +166,49 @@ def pin_to_gpu_numa(torch, dev_index):
         return {"pinned": False, "why": f"{type(e).__name__}: {e}"[:80]}
 
 
+# What the first multi-GPU run is expected to show (written down BEFORE it: no multi-GPU node was available to any round).
+# Inputs: this run's own one-GPU step time; the one-GPU emulation of rank 0's receive load (profiles/r05_rccl_contention.json:
+# 7 inbound shards cost the receiving rank's loop 4.0 %, 1 shard 0.4 % -- taken as linear in the number of senders); the
+# gather's size (one float32 disparity shard per sender and step) over one xGMI link each (~153 GB/s per link and direction
+# pair, /opt/skills/guides/MI355X_MICROARCH.md), asynchronous and double-buffered, i.e. exposed only where it outlasts a step.
+XGMI_LINK_GBS = 153.0
+ROOT_SLOWDOWN_PER_SENDER = 0.04 / 7
+NEAR_LINEAR_EFFICIENCY = 0.93
+
+
+def predict_scaling(ms_per_step_1gpu, batch, h, w, d, worlds=(1, 2, 4, 8)):
+    """Predicted weak-scaling curve of `bench.py --gpus N`: per N the step time of the slowest rank (rank 0: it receives), the
+    gather's bytes and duration, the part of it a step cannot hide, whole-job throughput and efficiency against N x one GPU."""
+    shard_bytes = batch * h * w * 4
+    rows = []
+    for n in worlds:
+        root_ms = ms_per_step_1gpu * (1.0 + ROOT_SLOWDOWN_PER_SENDER * (n - 1))
+        gather_ms = shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 if n > 1 else 0.0   # one link per sender, all in parallel
+        exposed = max(0.0, gather_ms - root_ms)
+        step_ms = root_ms + exposed
+        eff = ms_per_step_1gpu / step_ms
+        rows.append({"n_gpus": n, "ms_per_step_rank0": round(root_ms, 3), "ms_per_step_other_ranks": round(ms_per_step_1gpu, 3) if n > 1 else None,
+                     "gather_bytes_into_rank0": shard_bytes * (n - 1), "gather_ms_per_link": round(gather_ms, 3),
+                     "gather_exposed_ms": round(exposed, 3), "ms_per_step": round(step_ms, 3),
+                     "value_Mdisp_per_s": round(n * batch * h * w * d / step_ms / 1e3, 1), "efficiency": round(eff, 4)})
+    return {"model": "rank 0's loop slows by 4 % / 7 per sender (one-GPU emulation, profiles/r05_rccl_contention.json); the gather (one "
+                     "float32 shard per sender over its own xGMI link at ~153 GB/s) runs under the next step and is exposed only "
+                     "beyond a step; the other ranks run at the one-GPU rate; step = slowest rank",
+            "near_linear_means_efficiency_at_8_of_at_least": NEAR_LINEAR_EFFICIENCY, "from_ms_per_step_1gpu": round(ms_per_step_1gpu, 3),
+            "per_world": rows}
+
+
 def spawn_check(args):
-    """Launcher self-test (CPU, gloo): every rank reports its frame plan, rank 0 prints what it saw."""
+    """Launcher self-test (CPU, gloo): every rank reports its frame plan and what pinning to its GPU's NUMA node did (nothing,
+    without a GPU -- but the path runs), rank 0 prints what it saw."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     plan = frame_plan(args.batch, rank, world)
+    pin = pin_to_gpu_numa(torch, int(os.environ.get("LOCAL_RANK", "0")))
     seen = 1
-    rows = [[plan["lo"], plan["hi"], plan["seed0"]]]
+    rows = [[plan["lo"], plan["hi"], plan["seed0"], int(bool(pin.get("pinned")))]]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -186,7 +220,9 @@ def spawn_check(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"n_gpus": world, "ranks_seen": seen, "frames_per_step": plan["n_total"], "plan": rows}), flush=True)
+        print(json.dumps({"n_gpus": world, "ranks_seen": seen, "frames_per_step": plan["n_total"], "plan": [r[:3] for r in rows],
+                          "pinned": [r[3] for r in rows], "pin_rank0": pin,
+                          "predicted": predict_scaling(8.25, args.batch, H, W, D)}), flush=True)
     return 0
 
 
@@ -238,11 +274,34 @@ def cpu_baseline(n_frames, gpu_out=None):
                 sample=f"{n_frames} full {H}x{W}x{D} frames (occlusion heuristic + VPP rnd + rSGM), oracle/liboracle.so "
                        f"gcc {_oracle_flags().split(' -fPIC')[0]}, 1 thread, {t_tot / n_frames:.2f} s/frame, "
                        f"host has {os.cpu_count()} cpus; the port's rSGM is scalar C, about an order of magnitude slower than the "
-                       "SSE rSGM of the literature (SURVEY section 6): the GPU/CPU ratio is not a kernel-quality figure.  Calibration "
+                       "SSE rSGM of the literature (SURVEY section 6; `cpu_baseline_simd` is the same port with an AVX2 aggregation): the GPU/CPU ratio is not a kernel-quality figure.  Calibration "
                        "against the real reference (profiles/r05_cpu_calibration.json, tools/calibrate_cpu.py): the VPP half of the port "
                        "takes 0.49x the time of the reference's Cython scan (5.4 vs 10.9 ms per frame, bit-identical); the rSGM half "
                        "(> 99 % of the time) cannot be calibrated, pyrSGM is not in the reference's tree")
     return base, epe
+
+
+def cpu_baseline_simd(n_frames, gpu_out=None):
+    """The same port with the aggregation -- three quarters of the scalar port's time -- on AVX2 (oracle/rsgm_oracle.c,
+    aggregate_paths_avx2: adds_epu16 / min_epu16 / minpos, bit-equal to the scalar function): the KIND of code the reference's
+    natives are (SSE, one thread: rsgm.py:44,61).  Still a port, still one thread; the scalar leg stays `cpu_baseline` and the
+    checker."""
+    import oracle
+    oracle.set_simd(True)
+    try:
+        t_tot, epe = 0.0, None
+        for f in range(n_frames):
+            dt, disp = _cpu_one_frame(f)
+            t_tot += dt
+            if gpu_out is not None and f < gpu_out.shape[0]:
+                e = float(abs(disp - gpu_out[f]).mean())
+                epe = e if epe is None else max(epe, e)
+    finally:
+        oracle.set_simd(False)
+    return dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port", s_per_frame=round(t_tot / n_frames, 3),
+                epe_vs_gpu=epe, flags=_oracle_flags().split(' -fPIC')[0],
+                sample=f"{n_frames} full {H}x{W}x{D} frames, the oracle with its AVX2 aggregation twin (16 disparities per vector; cost, WTA and "
+                       "the Python-glue stages stay scalar C), 1 thread")
 
 
 def cpu_baseline_parallel():
@@ -678,7 +737,10 @@ def run_rank(args):
                       "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
                       "ms_per_step_per_rank": [round(x, 3) for x in rank_ms],
                       "gather_wait_ms_per_step_per_rank": [round(x, 3) for x in rank_gather_ms] if world > 1 else None,
-                      "numa_node_per_rank": rank_numa if world > 1 else None},
+                      "numa_node_per_rank": rank_numa if world > 1 else None,
+                      # the curve the first multi-GPU run is to be checked against, from this run's own
+                      # one-GPU step time when N = 1, else from the slowest non-root rank
+                      "predicted": predict_scaling(ms_per_step if world == 1 else (sorted(rank_ms)[0] if rank_ms else ms_per_step), B, H, W, D)},
             # The dominant kernel (bench contract): SURVEY 8d's algorithmic bytes of the launch -- 10 B/cell for the 8-path
             # aggregation, pro rata for the paths the launch carries -- over its average duration inside the timed steps
             # (hipEvent pairs on the launch stream), against the HBM3E peak; `traffic` = the launch's real HBM bytes (PMC).
@@ -720,6 +782,7 @@ def run_rank(args):
             result["cpu_baseline"], epe = cpu_baseline(min(args.cpu_frames, n_unique), gpu_out)
             result["epe_vs_cpu_oracle"] = epe      # mean |disp_gpu - disp_cpu|, worst frame (0.0 = bit-equal)
             result["speedup_vs_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+            result["cpu_baseline_simd"] = cpu_baseline_simd(min(args.cpu_frames, n_unique), gpu_out)
             if not args.no_cpu_parallel:
                 result["cpu_baseline_all_cores"] = cpu_baseline_parallel()
         else:
@@ -759,6 +822,17 @@ def run_rank(args):
             sweep.append({"frames_per_call": B, "ms_per_call": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step / B, 4),
                           "Mdisparities_per_s": round(value, 1), "roofline_frac": round(pipeline_gbs / HBM_PEAK_GBS, 4), "aggregation_layout": layout})
             result["batch_sweep"] = sweep
+            # ---- the same path for a caller that holds ONE pageable numpy frame at a time (test.py:291-311, then :154-225 per frame):
+            # vppstereo_amd.pipeline.FrameStream (vppx_fstream_*).  PCIe inclusive, host copies inclusive: never `value`.
+            try:
+                from tools import host_stream as hs
+                result["host_stream"] = {
+                    "what": "pipeline.FrameStream: frames pushed one at a time from pageable numpy arrays, disparities popped one at a time into "
+                            "fresh numpy arrays, in input order; occlusion mask on the way; batches of one lock-step round, depth 2; ms per frame "
+                            "next to pipeline.run_frame (one synchronous call per frame) and the PCIe floor of the bytes that cross",
+                    "runs": [hs.measure(H, W, D, P_HINTS, 192), hs.measure(375, 1242, 192, 0.05, 192)]}
+            except Exception as e:  # noqa: BLE001  (a measurement next to the headline: its failure must not lose the line)
+                result["host_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

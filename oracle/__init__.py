@@ -193,10 +193,21 @@ def costMeasureCensus5x5_xyd_SSE(cl, cr, dsi, w, h, dmax, nthreads=1):
                                    int(dmax))
 
 
-def aggregate_SSE(img, dsi, dsi_agg, w, h, dmax, p1, p2min, alpha, gamma, path_mask=0xFF):
+def aggregate_SSE(img, dsi, dsi_agg, w, h, dmax, p1, p2min, alpha, gamma, path_mask=0xFF, simd=False):
+    """simd=True: the AVX2 twin (rsgmo_aggregate_paths_simd), bit-equal; the scalar function is the checker."""
     assert img.dtype == np.uint8 and img.shape == (h, w)
-    lib().rsgmo_aggregate_paths(_u8(img), _p(dsi, C.c_uint16), _p(dsi_agg, C.c_uint16), int(w), int(h), int(dmax),
-                                int(p1), int(p2min), C.c_float(alpha), int(gamma), int(path_mask))
+    fn = lib().rsgmo_aggregate_paths_simd if simd else lib().rsgmo_aggregate_paths
+    fn(_u8(img), _p(dsi, C.c_uint16), _p(dsi_agg, C.c_uint16), int(w), int(h), int(dmax),
+       int(p1), int(p2min), C.c_float(alpha), int(gamma), int(path_mask))
+
+
+def set_simd(on):
+    """compute_rsgm aggregates with the AVX2 twin from here on (bench.py's `cpu_baseline_simd` leg only; off by default)."""
+    lib().rsgmo_set_simd(int(bool(on)))
+
+
+def get_simd():
+    return bool(lib().rsgmo_get_simd())
 
 
 def _guided_dsi(dsi, hints, validhints):

@@ -38,3 +38,42 @@ def test_failed_rank_gives_nonzero_exit():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--cpu-frames", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+def test_gpus_8_self_spawns_eight_ranks_with_the_numa_path_and_the_prediction():
+    """`--gpus 8 --spawn-check` on a box without GPUs: eight gloo ranks, a partition of 8 x 4 frames with sharding-independent
+    seeds, the NUMA pinning path taken (and harmless) on every rank, and the written-down prediction in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "4", "--spawn-check"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["frames_per_step"] == 32
+    assert line["plan"] == [[4 * i, 4 * i + 4, 1 + 4 * i] for i in range(8)]
+    assert len(line["pinned"]) == 8 and "pinned" in line["pin_rank0"]
+    pw = {p["n_gpus"]: p for p in line["predicted"]["per_world"]}
+    assert set(pw) == {1, 2, 4, 8}
+
+
+def test_uneven_shards_30_frames_over_8_ranks():
+    """A total that the ranks do not divide: contiguous blocks whose sizes differ by at most one, seeds by global frame index,
+    and the gather's padding arithmetic (every rank sends ceil(30 / 8) frames, the root cuts the padding off)."""
+    from vppstereo_amd import dist as vdist
+    blocks = [vdist.shard_range(30, r, 8) for r in range(8)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == 30
+    assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    sizes = [hi - lo for lo, hi in blocks]
+    assert sizes == [4, 4, 4, 4, 4, 4, 3, 3] and max(sizes) == (30 + 7) // 8
+    assert [vdist.frame_seed(7, lo) for lo, _ in blocks] == [7 + lo for lo, _ in blocks]
+    assert vdist.frame_seed(0xFFFFFFFF, 3) == 2          # srand() takes 32 bits
+
+
+def test_scaling_prediction_is_what_design_section_10_states():
+    p = bench.predict_scaling(8.25, 32, 540, 960, 192)
+    rows = {r["n_gpus"]: r for r in p["per_world"]}
+    assert rows[1]["efficiency"] == 1.0 and rows[1]["gather_bytes_into_rank0"] == 0
+    assert rows[8]["gather_bytes_into_rank0"] == 7 * 32 * 540 * 960 * 4          # 7 x 66 MB
+    assert 0.42 < rows[8]["gather_ms_per_link"] < 0.45 and rows[8]["gather_exposed_ms"] == 0.0
+    assert abs(rows[8]["ms_per_step"] - 8.25 * 1.04) < 0.01 and abs(rows[2]["ms_per_step"] - 8.25 * (1 + 0.04 / 7)) < 0.01
+    assert rows[8]["efficiency"] >= p["near_linear_means_efficiency_at_8_of_at_least"]
+    assert rows[2]["efficiency"] > rows[4]["efficiency"] > rows[8]["efficiency"]

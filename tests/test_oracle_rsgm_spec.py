@@ -196,3 +196,49 @@ def test_gray_pad_speckle():
     out = img.copy()
     oracle.filterSpeckles(out, 0, 200, 10)
     assert not out[2:6, 2:6].any() and (out[8:19, 5:29] > 0).all() and out[9, 6] == 88
+
+
+@pytest.mark.parametrize("D", [16, 64, 192])
+def test_avx2_aggregation_twin_is_bit_equal_to_the_scalar_checker(D):
+    """`cpu_baseline_simd` times the oracle with its AVX2 aggregation (adds_epu16 / min_epu16: the kind of code the reference's
+    SSE natives are): it must be the same function -- every path alone, all eight together, saturating inputs included."""
+    rng = np.random.default_rng(D)
+    h, w = 9, 23
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    for case in range(3):
+        if case == 0:
+            dsi = rng.integers(0, 25, (h, w, D)).astype(np.uint16)
+            p1, p2min, alpha, gamma = 11, 17, 0.5, 35
+        elif case == 1:
+            dsi = rng.integers(0, 65536, (h, w, D)).astype(np.uint16)          # saturation everywhere
+            p1, p2min, alpha, gamma = 40000, 30000, 100.0, 60000
+        else:
+            dsi = rng.integers(0, 400, (h, w, D)).astype(np.uint16)
+            p1, p2min, alpha, gamma = 0, 0, 0.25, 200
+        for mask in [1 << k for k in range(8)] + [0xFF, 0x0F, 0xA5]:
+            a, b = np.empty_like(dsi), np.empty_like(dsi)
+            oracle.aggregate_SSE(img, dsi, a, w, h, D, p1, p2min, alpha, gamma, path_mask=mask)
+            oracle.aggregate_SSE(img, dsi, b, w, h, D, p1, p2min, alpha, gamma, path_mask=mask, simd=True)
+            assert np.array_equal(a, b), (case, mask)
+
+
+def test_avx2_twin_falls_back_where_it_does_not_apply_and_compute_rsgm_is_unchanged_by_the_flag():
+    rng = np.random.default_rng(5)
+    h, w, D = 6, 20, 24                                   # D % 16 != 0: the scalar function runs
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    dsi = rng.integers(0, 25, (h, w, D)).astype(np.uint16)
+    a, b = np.empty_like(dsi), np.empty_like(dsi)
+    oracle.aggregate_SSE(img, dsi, a, w, h, D, 11, 17, 0.5, 35)
+    oracle.aggregate_SSE(img, dsi, b, w, h, D, 11, 17, 0.5, 35, simd=True)
+    assert np.array_equal(a, b)
+    oracle.aggregate_SSE(img, dsi[..., :16].copy(), a[..., :16].copy(), w, h, 16, 11, -5, 0.5, -40, simd=True)   # negative P2: scalar path, no crash
+    import synth
+    fr = synth.make_frame(40, 96, 64, 0.05, seed=3)
+    assert not oracle.get_simd()
+    want = oracle.compute_rsgm(fr["left"], fr["left"], fr["right"], dmax=64)
+    oracle.set_simd(True)
+    try:
+        got = oracle.compute_rsgm(fr["left"], fr["left"], fr["right"], dmax=64)
+    finally:
+        oracle.set_simd(False)
+    assert np.array_equal(want, got)

@@ -26,6 +26,18 @@ def measure(H, W, D, p, n_frames, batch=None, depth=2, copy_threads=-1, pool=8, 
     with pipeline.FrameStream(H, W, 3, batch=batch, depth=depth, seed=1, copy_threads=copy_threads, **kw) as fs:
         for _ in fs.run((frames[i % pool]) for i in range(fs.batch * 2)):
             pass
+        # where the host's time goes: seconds inside push (the copy into the ring + a batch's submission) and inside the native pop
+        # (waiting for the batch + the copy out), the rest is Python
+        tp = [0.0, 0.0]
+        push0, pop0 = fs.push, fs._pop_native
+
+        def push1(*a):
+            t = time.perf_counter(); push0(*a); tp[0] += time.perf_counter() - t
+
+        def pop1():
+            t = time.perf_counter(); r = pop0(); tp[1] += time.perf_counter() - t
+            return r
+        fs.push, fs._pop_native = push1, pop1
         t0 = time.perf_counter()
         n = 0
         acc = 0.0
@@ -35,6 +47,8 @@ def measure(H, W, D, p, n_frames, batch=None, depth=2, copy_threads=-1, pool=8, 
         dt = time.perf_counter() - t0
         assert n == n_frames
         res["reruns"] = fs.counts()[3]
+        res["host_ms_per_frame"] = {"push": round(tp[0] / n_frames * 1e3, 4), "pop": round(tp[1] / n_frames * 1e3, 4),
+                                    "python_rest": round((dt - tp[0] - tp[1]) / n_frames * 1e3, 4)}
     res["stream_ms_per_frame"] = round(dt / n_frames * 1e3, 4)
     res["stream_Mdisp_per_s"] = round(H * W * D / (dt / n_frames) / 1e6, 1)
     up, down = H * W * (3 + 3 + 4), H * W * 4
@@ -55,7 +69,7 @@ if __name__ == "__main__":
     n = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 256
     out = {"what": "FrameStream: pageable numpy in, numpy out, one frame at a time (ms per frame, PCIe inclusive)", "runs": []}
     for (H, W, D, p) in ((540, 960, 192, 0.03), (375, 1242, 192, 0.05)):
-        for thr in (-1, 1):
+        for thr in (-1, 1, 2, 8):
             r = measure(H, W, D, p, n, copy_threads=thr, with_run_frame=(thr == -1))
             r["copy_threads"] = thr
             out["runs"].append(r)

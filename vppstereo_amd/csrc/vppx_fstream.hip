@@ -48,76 +48,77 @@ public:
     void copy(const CopyJob *jobs, int n)
     {
         const size_t piece = 256 * 1024;
-        std::vector<CopyJob> pieces;
+        pieces_.clear();
         for (int i = 0; i < n; i++) {
             if (!jobs[i].dst || !jobs[i].src) continue;
             for (size_t o = 0; o < jobs[i].bytes; o += piece)
-                pieces.push_back({(char *)jobs[i].dst + o, (const char *)jobs[i].src + o, jobs[i].bytes - o < piece ? jobs[i].bytes - o : piece});
+                pieces_.push_back({(char *)jobs[i].dst + o, (const char *)jobs[i].src + o, jobs[i].bytes - o < piece ? jobs[i].bytes - o : piece});
         }
-        if (pieces.empty()) return;
-        if (workers_.empty() || pieces.size() == 1) {
-            for (auto &p : pieces) memcpy(p.dst, p.src, p.bytes);
+        if (pieces_.empty()) return;
+        if (workers_.empty() || pieces_.size() == 1) {
+            for (auto &p : pieces_) memcpy(p.dst, p.src, p.bytes);
             return;
         }
         {
             std::lock_guard<std::mutex> lk(m_);
-            cur_ = &pieces;
             next_.store(0);
-            left_ = (int)pieces.size();
-            gen_++;
+            left_.store((int)pieces_.size());
+            open_ = true;
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        work(pieces);
+        work();
+        // the other threads' last pieces: a few microseconds, not worth a sleep
+        for (int spin = 0; spin < 100000 && (left_.load(std::memory_order_acquire) != 0 || active_.load(std::memory_order_acquire) != 0); spin++)
+            __builtin_ia32_pause();
         std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return left_ == 0 && active_ == 0; });
-        cur_ = nullptr;
+        done_.wait(lk, [this] { return left_.load() == 0 && active_.load() == 0; });
+        open_ = false; // (workers that wake up late find nothing to join)
     }
 
 private:
-    void work(std::vector<CopyJob> &pieces)
+    void work()
     {
         int mine = 0;
         for (;;) {
             const size_t i = next_.fetch_add(1);
-            if (i >= pieces.size()) break;
-            memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes);
+            if (i >= pieces_.size()) break;
+            memcpy(pieces_[i].dst, pieces_[i].src, pieces_[i].bytes);
             mine++;
         }
-        if (mine) {
-            std::lock_guard<std::mutex> lk(m_);
-            left_ -= mine;
-            if (left_ == 0) done_.notify_all();
-        }
+        if (mine) left_.fetch_sub(mine, std::memory_order_release);
     }
     void run()
     {
         unsigned seen = 0;
         for (;;) {
-            std::vector<CopyJob> *p;
+            // frames of a running stream follow each other within a few hundred microseconds: look for the next one for a while
+            // before going to sleep (a condition variable's wake-up costs as much as the copy it is woken for)
+            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; spin++) __builtin_ia32_pause();
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && cur_); });
+                cv_.wait(lk, [&] { return stop_ || gen_.load() != seen; });
                 if (stop_) return;
-                seen = gen_;
-                p = cur_;
-                active_++;
+                seen = gen_.load();
+                if (!open_) continue; // that copy is over already
+                active_.fetch_add(1);
             }
-            work(*p);
+            work();
             {
                 std::lock_guard<std::mutex> lk(m_);
-                active_--;
-                if (left_ == 0 && active_ == 0) done_.notify_all();
+                active_.fetch_sub(1, std::memory_order_release);
             }
+            done_.notify_all();
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_, done_;
-    std::vector<CopyJob> *cur_ = nullptr;
+    std::vector<CopyJob> pieces_;
     std::atomic<size_t> next_{0};
-    int left_ = 0, active_ = 0;
-    unsigned gen_ = 0;
-    bool stop_ = false;
+    std::atomic<int> left_{0}, active_{0};
+    std::atomic<unsigned> gen_{0};
+    bool open_ = false, stop_ = false;
 };
 
 struct Slot {

@@ -132,7 +132,8 @@ class FrameStream:
         except _lib.VppxError as e:
             self._ctx.close()
             raise Exception(str(e)) from e
-        self._pushed = self._popped = self._submitted = 0
+        self._pushed = self._popped = self._fill = 0
+        self._inflight = []       # frames not yet popped of every submitted batch, oldest first (at most `depth` batches)
         self._early = []          # results popped to make room, oldest first
         self.last_draws = 0
 
@@ -178,8 +179,8 @@ class FrameStream:
         elif g_occ is not None:
             raise ValueError("g_occ given but the stream was created without with_g_occ=True")
         # the ring holds `depth` submitted batches: before the frame that would start one more, take the oldest batch's results
-        if self._pushed % self.batch == 0:
-            while self._submitted - self._popped > (self.depth - 1) * self.batch:
+        if self._fill == 0:
+            while len(self._inflight) >= self.depth:
                 self._early.append(self._pop_native())
         try:
             _lib.check(self._lib.vppx_fstream_push(self._h, left.ctypes.data, right.ctypes.data, hints.ctypes.data,
@@ -187,8 +188,10 @@ class FrameStream:
         except _lib.VppxError as e:
             raise Exception(str(e)) from e
         self._pushed += 1
-        if self._pushed % self.batch == 0:
-            self._submitted = self._pushed
+        self._fill += 1
+        if self._fill == self.batch:
+            self._inflight.append(self._fill)
+            self._fill = 0
 
     def flush(self):
         """Submit the frames pushed so far as a smaller batch (end of the sequence, or a latency bound)."""
@@ -196,10 +199,9 @@ class FrameStream:
             _lib.check(self._lib.vppx_fstream_flush(self._h))
         except _lib.VppxError as e:
             raise Exception(str(e)) from e
-        if self._pushed % self.batch:
-            # a short batch moves the boundary: later batches are counted from here
-            self._submitted = self._pushed
-            self._pushed_base = self._pushed
+        if self._fill:
+            self._inflight.append(self._fill)
+            self._fill = 0
 
     # ---- one frame out ----
     def _pop_native(self):
@@ -219,6 +221,9 @@ class FrameStream:
         if not got.value:
             return None
         self._popped += 1
+        self._inflight[0] -= 1
+        if self._inflight[0] == 0:
+            self._inflight.pop(0)
         return ((disp, lc, rc, conf) if self._patterns else disp), int(draws.value)
 
     def pop(self):
@@ -247,7 +252,7 @@ class FrameStream:
             # whole batches that must be complete by now: everything but the last depth - 1 submitted ones
             while self._early:
                 yield self.pop()
-            while self._submitted - self._popped > (self.depth - 1) * self.batch:
+            while len(self._inflight) >= self.depth:
                 yield self.pop()
         self.flush()
         while True:
