@@ -1,3 +1,4 @@
+"""tools/cfg5_probe.py: pipelined steps of 8 frames of 1536x2048x256 (cfg 5 per GPU) with the stage times of one un-overlapped step."""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch

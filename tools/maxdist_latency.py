@@ -1,3 +1,4 @@
+"""tools/maxdist_latency.py: one 540x960 frame through the maxDistance colour method (Engine.vpp), ms per call."""
 import sys, time, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import synth
