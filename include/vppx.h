@@ -424,7 +424,7 @@ const char *vppx_stage_name(int i);
  *   VPPX_VARIANT        comma-separated tokens that select alternative kernels with identical results, each run by
  *                       tests/test_gpu_variants.py: sum_general, sum_gl8, sum_trap0, sum_trap1 (fused sum / WTA kernel), gw4, gw8,
  *                       gw16 (lanes per pixel of the line-parallel kernel), we_line (W / E on the line-parallel kernel), we_after (W / E never next to
- *                       an under-filled lock-step launch), v4_wpe3 (D = 192: the 16-pixel lock-step kernel built for 3 waves per SIMD),
+ *                       an under-filled lock-step launch),
  *                       maxdist_lds, maxdist_global (one-wave maxDistance kernels) */
 
 #ifdef __cplusplus

@@ -1921,8 +1921,8 @@ __device__ __forceinline__ u32 sgm_update_split_pn(u32 (&L)[NP], const u32 (&C)[
     return min(m[0] & 0xFFFFu, m[0] >> 16);
 }
 
-template <int DPL, int WPE = 2> // WPE: waves per SIMD the register budget is cut for (3: 168 VGPRs at DPL = 48, 20 of them spilled)
-__global__ void __launch_bounds__(256, WPE) sgm_vert4_kernel(Vert3Args a)
+template <int DPL>
+__global__ void __launch_bounds__(256, 2) sgm_vert4_kernel(Vert3Args a)
 {
     constexpr int NP = DPL / 2, D = 4 * DPL, V3_XW = V3Rec<NP>::XW;
     static_assert(NP % 4 == 0, "edge records are made of 16-byte pieces");
@@ -2183,9 +2183,7 @@ int rsgm_vert3_probe(vppx_ctx *ctx, u32 *scratch_dev /* >= 256 words */, bool *o
     ctx->v3.blocks_per_cu[2] = v3_blocks_per_cu<24>();
     ctx->v3.blocks_per_cu[3] = v3_blocks_per_cu<32>();
     {
-        // VPPX_VARIANT=v4_wpe3 (measured, not the default: NOTEBOOK round 6): D = 192 on the 3-waves-per-SIMD build of the kernel
-        const void *wide_fn[4] = {(const void *)sgm_vert4_kernel<16>, (const void *)sgm_vert4_kernel<32>,
-                                  ctx->knobs.v4_wpe3 ? (const void *)sgm_vert4_kernel<48, 3> : (const void *)sgm_vert4_kernel<48>,
+        const void *wide_fn[4] = {(const void *)sgm_vert4_kernel<16>, (const void *)sgm_vert4_kernel<32>, (const void *)sgm_vert4_kernel<48>,
                                   (const void *)sgm_vert4_kernel<64>};
         for (int k = 0; k < 4; k++) {
             int n = 0;
@@ -2353,7 +2351,6 @@ int rsgm_launch_vert3_range(vppx_ctx *ctx, hipStream_t stream, int B_total, int 
     const dim3 grid((unsigned)((2 * nB + 7) / 8 * 8 * a.nbg)); // whole rounds of 8 groups; groups >= 2 nB exit at once
     if (wide && D == 64) sgm_vert4_kernel<16><<<grid, 256, 0, stream>>>(a);
     else if (wide && D == 128) sgm_vert4_kernel<32><<<grid, 256, 0, stream>>>(a);
-    else if (wide && D == 192 && ctx->knobs.v4_wpe3) sgm_vert4_kernel<48, 3><<<grid, 256, 0, stream>>>(a);
     else if (wide && D == 192) sgm_vert4_kernel<48><<<grid, 256, 0, stream>>>(a);
     else if (wide) sgm_vert4_kernel<64><<<grid, 256, 0, stream>>>(a);
     else if (D == 64) sgm_vert3_kernel<8><<<grid, 256, 0, stream>>>(a);

@@ -170,7 +170,6 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
             if (has("sum_trap0")) ctx->knobs.sum_trap = 0;
             if (has("sum_trap1")) ctx->knobs.sum_trap = 1;
             if (has("we_after")) ctx->knobs.we_next = 0;
-            if (has("v4_wpe3")) ctx->knobs.v4_wpe3 = 1;
 #ifdef VPPX_EXPERIMENT
             if (has("pipe_mid")) ctx->pipe_mid = true; // the next front stage starts behind the vertical kernel, next to W/E (measured: 9.16 -> 9.6 ms per step)
             const size_t sb = v.find("sum_blocks=");

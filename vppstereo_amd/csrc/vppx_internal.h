@@ -148,7 +148,6 @@ struct vppx_ctx {
         int sum_gl8 = 0;      // "sum_gl8": 8 lanes per pixel in the fused sum / WTA kernel (D = 128 / 192)
         int sum_trap = 2;     // D = 256, fused layout: trapezoid ring with spare slots; "sum_trap1": without them; "sum_trap0": uniform ring, 32-pixel rounds
         int we_next = 1;      // W/E next to an under-filled lock-step launch (rsgm_vert3_plan); "we_after": always behind it
-        int v4_wpe3 = 0;      // "v4_wpe3": D = 192, 16 pixels per wave: the kernel built for 3 waves per SIMD (168 VGPRs, 20 spilled): 3 blocks per CU
         int sum_blocks = 0;   // (experiment builds) "sum_blocks=N": forced number of blocks of the sum / WTA kernel
     } knobs;
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
