@@ -424,7 +424,7 @@ const char *vppx_stage_name(int i);
  *   VPPX_VARIANT        comma-separated tokens that select alternative kernels with identical results, each run by
  *                       tests/test_gpu_variants.py: sum_general, sum_gl8, sum_trap0, sum_trap1 (fused sum / WTA kernel), gw4, gw8,
  *                       gw16 (lanes per pixel of the line-parallel kernel), we_line (W / E on the line-parallel kernel), we_after (W / E never next to
- *                       an under-filled lock-step launch),
+ *                       an under-filled lock-step launch), we_lq0, we_lq1 (W / E kernel: left-view operands per step / per quad of steps), we_whole (W / E kernel: no line of the last layer of waves is cut into pieces; tests: we_layer=N takes a layer to be N waves, we_mute makes every later piece give up waiting and compute its line from the start),
  *                       maxdist_lds, maxdist_global (one-wave maxDistance kernels) */
 
 #ifdef __cplusplus

@@ -275,3 +275,46 @@ def test_trapezoid_ring_at_d256_every_width(engines, B, H, W):
     oracle.init_rand(3)
     lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
     assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, dmax=256, subpixel=False, p1=7, p2min=13, gamma=40), a[0].cpu().numpy())
+
+
+# (D, B, H, W, layer): `we_layer=N` makes the W/E launcher take a layer of waves to be N (the device's SIMD count on a real launch), so
+# that small launches have a part-filled last layer whose lines are cut into pieces: 2 x B x Hp / 4 line quads = whole layers + a tail;
+# c pieces per tail line, c in 2..8 with the smallest ceil(tail * c / layer) / c, if that is below 0.9 (launch_we12).
+_SPLIT_CASES = [
+    (192, 8, 20, 96, 60),      # 128 line quads = 2 x 60 + 8: 2 pieces of 4 groups, both boundaries inside the d > x columns
+    (192, 8, 20, 330, 90),     # 128 = 90 + 38: 7 pieces of 4 groups over 28 (load 3 / 7)
+    (192, 9, 37, 200, 100),    # 216 = 2 x 100 + 16: 2 pieces over 18 groups, the last of them a part of a group (208 columns)
+    (128, 8, 33, 150, 89),     # D = 128 (8 steps per group): 192 = 2 x 89 + 14: 2 pieces over 20 groups
+    (256, 8, 12, 420, 61),     # D = 256 (16 steps per group): 64 = 61 + 3: 2 pieces over 27 groups
+    (192, 16, 60, 130, 200),   # 512 = 2 x 200 + 112: 7 pieces (load 4 / 7) over 12 groups: one group each, the last takes six
+    (192, 12, 28, 160, 97),    # 192 = 97 + 95: a tail of nearly a whole layer -- nothing is cut (same results either way)
+]
+
+
+@pytest.mark.parametrize("D,B,H,W,layer", _SPLIT_CASES)
+@pytest.mark.parametrize("lq", ["we_lq0", "we_lq1"])
+def test_we_lines_cut_into_pieces_equal_whole_lines(D, B, H, W, layer, lq):
+    """The W/E kernel cuts the lines of its last, part-filled layer of waves into pieces that hand the path state on through memory
+    (rsgm_kernels.hip, We12Args): the volumes -- and so every disparity -- must equal those of whole lines (`we_whole`) and of the
+    8-path layout, frame 0 the oracle's; and when no piece ever publishes (`we_mute`) every later piece gives up and computes its
+    line from the start: same values again."""
+    import torch
+    cut = _env_engine(VPPX_VERT=3, VPPX_VARIANT=f"{lq},we_layer={layer}")
+    whole = _env_engine(VPPX_VERT=3, VPPX_VARIANT=f"{lq},we_whole")
+    mute = _env_engine(VPPX_VERT=3, VPPX_VARIANT=f"{lq},we_layer={layer},we_mute")
+    eight = _env_engine(VPPX_VERT=0)
+    b = synth.make_batch(B, H, W, D, 0.05, seed=7700 + W)
+    args = [torch.from_numpy(np.ascontiguousarray(b[k])).to(cut.device) for k in ("left", "right", "hints")]
+    kw = dict(dmax=D, p1=9, p2min=14, gamma=41, alpha=0.5)
+    outs = []
+    for eng in (cut, whole, mute, eight):
+        for _ in range(2):           # twice: the second launch meets the first one's flags (another serial)
+            o = eng.vpp_rsgm(*args, seed=5, rsgm_kw=kw)
+            eng.synchronize()
+        outs.append(o)
+    assert cut.uses_vert() == 3 and whole.uses_vert() == 3 and mute.uses_vert() == 3 and eight.uses_vert() == 0
+    for o, name in zip(outs[:3], ("cut", "whole", "mute")):
+        assert torch.equal(o, outs[3]), (name, int((o != outs[3]).sum()))
+    oracle.init_rand(5)
+    lo, ro = oracle.vpp(b["left"][0], b["right"][0], b["hints"][0])
+    assert np.array_equal(oracle.compute_rsgm(b["left"][0], lo, ro, **kw), outs[0][0].cpu().numpy())

@@ -40,7 +40,7 @@ print("VARIANT_OK", int(eng.uses_vert()))   # how the LAST shape (8 frames, D = 
 @pytest.mark.parametrize("env", [dict(VPPX_VERT="1"), dict(VPPX_VERT="0"), dict(VPPX_VERT="3"), dict(VPPX_VARIANT="gw16"), dict(VPPX_VARIANT="gw4"),
                                  dict(VPPX_VARIANT="gw8"), dict(VPPX_SUBSTREAMS="2"), dict(VPPX_VERT="1", VPPX_SUBSTREAMS="2"),
                                  dict(VPPX_VERT="3", VPPX_SUBSTREAMS="2"), dict(VPPX_VARIANT="sum_general"), dict(VPPX_VARIANT="sum_gl8"),
-                                 dict(VPPX_VARIANT="we_line"), dict(VPPX_VARIANT="we_after"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap0"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap1,we_line"), dict()])
+                                 dict(VPPX_VARIANT="we_line"), dict(VPPX_VARIANT="we_after"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap0"), dict(VPPX_VERT="3", VPPX_VARIANT="sum_trap1,we_line"), dict(VPPX_VARIANT="we_whole"), dict(VPPX_VARIANT="we_lq0"), dict(VPPX_VARIANT="we_lq1"), dict()])
 def test_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)

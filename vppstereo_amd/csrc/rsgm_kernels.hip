@@ -956,6 +956,25 @@ struct We12Args {
     u8 *out;          // [2][B][Hp][Wp][D]: W, E
     int Hp, Wp, p1, B;
     size_t vol_elems;
+    // The last, part-filled layer of waves (round 6).  A launch is N equal waves of Wp dependent steps each; the chip takes them
+    // in layers of one wave per SIMD, and the N mod 1024 waves of the last layer occupy a fraction of the SIMDs for a whole
+    // line's time (16 frames of 540 x 960: 4.25 layers cost 5).  The lines of that last layer are therefore cut into `pieces`
+    // consecutive pieces of `piece_groups` groups of DPL steps, one wave per piece (blocks n_whole, n_whole + 1, ...: the last
+    // to be dispatched, one per SIMD): piece j waits -- asleep, issuing nothing -- until piece j - 1 of its line has left its
+    // path state (the lane's packed L values; everything else is reloaded) in `hand` and raised the line's flag, continues the
+    // line from there and passes it on.  A piece whose predecessor does not show up within `timeout_ticks` computes the line
+    // from its start itself: same values, no dependency, never a hang.
+    u32 *hand;        // [tail line][piece boundary][64 lanes][DPL / 2] dwords, then a flag per tail line: serial << 4 | pieces done
+    int n_whole;      // lines run whole: blocks [0, n_whole)
+    int lead;         // blocks in front of the grid that do nothing (a multiple of 8)
+    int ntail, tail_base, tail_pitch; // tail lines; first block of their pieces (a multiple of 8); blocks per piece index (a multiple of 8)
+    int pieces;       // pieces per tail line (1: nothing is cut)
+    int piece_groups; // groups per piece (the last piece takes what is left)
+    u32 serial;       // launch serial in the flags (a flag of another launch never matches)
+    long long timeout_ticks;
+#ifdef VPPX_EXPERIMENT
+    unsigned long long *trace; // experiment builds: per block (start, end) of the 100 MHz wall clock and HW_ID / XCC_ID (tools/we_trace.py)
+#endif
 };
 
 // DPL = disparities per lane = length of the window = steps per unrolled group (8, 12, 16: D = 128, 192, 256)
@@ -965,10 +984,15 @@ struct We12State {
     u32 L[DPL / 2];
     u32 minpk;
     u32 prevI;
+    // sets of per-quad operands of the left view, indexed by the quad's position in the unrolled group (compile time): two when a
+    // group holds an even number of quads, else one per quad
+    static constexpr int NS = (NQ % 2 == 0) ? 2 : NQ;
     u32 r[DPL];   // the window, rotating
     u32 T[NQ][4]; // new right-census words of this quad of steps and of the quads ahead
-    u32 CL[4];    // left census word / gray value of this step and of the three ahead
-    u32 GI[4];
+    u32 CLq[NS][4]; // LQ >= 1: left census words of this quad of steps and of the next one (one aligned 16-byte load per quad)
+    u32 Gq[NS];     // LQ >= 1 (LQ = 2: only these): their gray values, four to a dword
+    u32 CL[4];      // LQ = 0 / 2: left census word of this step and of the three ahead (a load per step)
+    u32 GI[4];      // LQ = 0: gray value likewise
 };
 
 // Addresses are "buffer resource of the frame + scalar position along the line + 32-bit lane offset" (what differs between
@@ -994,7 +1018,22 @@ __device__ __forceinline__ void we12_load_quad(u32 (&T)[4], const We12Lane &ln, 
     }
 }
 
-template <bool EAST, int DPL, int K>
+// The left census words and gray bytes of quad Q of a line's steps (W: pixels 4Q .. 4Q+3, E: Wp-4-4Q .. Wp-1-4Q, an aligned
+// quad either way): two loads per FOUR steps, a whole quad ahead of their first use.  (Until round 6 a word and a byte were
+// loaded per step; the byte's zero-extension sat right behind its load, so every step waited -- vmcnt(0): on gfx9 stores count
+// too -- for its own loads and for the previous step's volume store.)
+template <bool EAST, int DPL>
+__device__ __forceinline__ void we12_load_left_quad(u32 (&CLq)[4], u32 &Gq, const We12Lane &ln, int Q, int Wp)
+{
+    const int Qx = EAST ? Wp / 4 - 1 - Q : Q;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ln.cl, ln.cl_off, 16 * Qx, 0);
+    CLq[0] = v.x; CLq[1] = v.y; CLq[2] = v.z; CLq[3] = v.w;
+    Gq = __builtin_amdgcn_raw_buffer_load_b32(ln.gray, ln.gray_off, 4 * Qx, 0);
+}
+
+// LQ: how the left view's operands come in.  0: a census word and a gray byte per step, four steps ahead (rounds 4-5); 1: both per
+// quad of steps; 2: the gray bytes per quad, the census words per step.
+template <bool EAST, int DPL, int K, int LQ>
 __device__ __forceinline__ void we12_step(We12State<DPL> &st, const u32 *s_lut, const We12Lane &ln, int t0, int Wp, u32 P1pk, bool masked,
                                           int nquads)
 {
@@ -1005,17 +1044,24 @@ __device__ __forceinline__ void we12_step(We12State<DPL> &st, const u32 *s_lut, 
     const int x = EAST ? Wp - 1 - t : t;
     // ---- the step's new right-census word enters the window
     st.r[EAST ? (K + DPL - 1) % DPL : K] = st.T[K / 4][K % 4];
-    const u32 clv = st.CL[K % 4];
-    const u32 I = st.GI[K % 4];
-    // ---- operands of the steps ahead (scalar, clamped positions: t is wave-uniform)
-    {
+    constexpr int NS = We12State<DPL>::NS, SET = (K / 4) % NS, WI = EAST ? 3 - K % 4 : K % 4;
+    const u32 clv = LQ == 1 ? st.CLq[SET][WI] : st.CL[K % 4];
+    const u32 I = LQ == 0 ? st.GI[K % 4] : __builtin_amdgcn_ubfe(st.Gq[SET], 8 * WI, 8);
+    if (LQ != 1) { // ---- operands of the steps ahead (scalar, clamped positions: t is wave-uniform)
         int ta = t + 4;
         ta = ta < Wp ? ta : Wp - 1;
         const int xa = EAST ? Wp - 1 - ta : ta;
         st.CL[K % 4] = __builtin_amdgcn_raw_buffer_load_b32(ln.cl, ln.cl_off, 4 * xa, 0);
-        st.GI[K % 4] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
+        if (LQ == 0) st.GI[K % 4] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
     }
-    if (K % 4 == 0) { // (the set refilled here held the words of the quad before this one)
+    if (K % 4 == 0) {
+        // ---- operands of the quads ahead; the sets refilled here held the words of the quad before this one
+        if (LQ != 0) {
+            int Qn = t / 4 + 1;
+            Qn = Qn < nquads ? Qn : nquads - 1;
+            if (LQ == 1) we12_load_left_quad<EAST, DPL>(st.CLq[(K / 4 + 1) % NS], st.Gq[(K / 4 + 1) % NS], ln, Qn, Wp);
+            else st.Gq[(K / 4 + 1) % NS] = __builtin_amdgcn_raw_buffer_load_b32(ln.gray, ln.gray_off, 4 * (EAST ? Wp / 4 - 1 - Qn : Qn), 0);
+        }
         int Q = t / 4 + AHEAD;
         Q = Q < nquads ? Q : nquads - 1;
         we12_load_quad<EAST, DPL>(st.T[(K / 4 + AHEAD) % NQ], ln, Q, Wp);
@@ -1056,29 +1102,67 @@ __device__ __forceinline__ void we12_step(We12State<DPL> &st, const u32 *s_lut, 
     else __builtin_amdgcn_raw_buffer_store_b128(u32x4{bw[0], bw[1], bw[2], bw[3]}, ln.out, ln.out_off, D * x, 2);
 }
 
-template <bool EAST, int DPL, int K0, int KN>
+template <bool EAST, int DPL, int K0, int KN, int LQ>
 __device__ __forceinline__ void we12_steps(We12State<DPL> &st, const u32 *s_lut, const We12Lane &ln, int t0, int Wp, u32 P1pk, bool masked,
                                            int nquads)
 {
     if constexpr (K0 < KN) {
-        we12_step<EAST, DPL, K0>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
-        we12_steps<EAST, DPL, K0 + 1, KN>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_step<EAST, DPL, K0, LQ>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_steps<EAST, DPL, K0 + 1, KN, LQ>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
     }
 }
 
-template <bool EAST, int DPL>
-__device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, const We12Lane &ln, u32 P1pk)
+// Steps [g0 * DPL, g1 * DPL) of a line.  g0 > 0: the line's state after step g0 * DPL - 1 comes from `hand_in` once `flag` says
+// so; g1 * DPL < Wp: the state goes to `hand_out` and the flag is raised to `piece + 1`.
+template <bool EAST, int DPL, int LQ>
+__device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, const We12Lane &ln, u32 P1pk, int g0, int g1, int piece,
+                                          const u32 *hand_in, u32 *hand_out, u32 *flag)
 {
-    constexpr int NQ = DPL / 4, D = 16 * DPL;
+    constexpr int NP = DPL / 2, NQ = DPL / 4, D = 16 * DPL;
     constexpr int AHEAD = NQ >= 3 ? 2 : 1;
     const int Wp = a.Wp, nquads = Wp / 4;
     We12State<DPL> st;
+    if (g0 > 0) {
+        // wait for the piece before this one (wave-uniform; s_sleep keeps the wave off the issue ports its SIMD's other waves need)
+        const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
+        bool there = false;
+        for (;;) {
+            // (readfirstlane: what the flag says is the same for the whole wave, and the compiler must know it -- every position
+            // of the line below is a scalar; without it each load and store was wrapped in a waterfall loop: W/E + 10 %)
+            const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if ((v >> 4) == (a.serial & 0x0FFFFFFFu) && (int)(v & 15u) >= piece) { there = true; break; }
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t_start > a.timeout_ticks) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (!there) g0 = 0; // nobody came: the whole line up to g1, alone (same values)
+        g0 = __builtin_amdgcn_readfirstlane(g0);
+    }
+    if (g0 > 0) {
+        // The record was written on another CU of the SAME XCD (the pieces of a line are blocks 8 apart, and consecutive block ids
+        // go round-robin over the XCDs: rsgm_vert3_probe has checked that): the hand-off goes through that XCD's L2 like the
+        // lock-step kernel's edge records -- sc1 loads (the CU's L1 bypassed) of what sc1 stores put there, no cache-wide
+        // invalidate or write-back.  (Across XCDs the same loads may meet a stale line of the reader's own L2: one wrong frame in
+        // a full-size test; an acquire / release fence pair per piece is right but costs every wave of the XCD its cached lines.)
+        asm volatile("" ::: "memory");
+        const u32 *hp = hand_in + (threadIdx.x & 63) * NP;
 #pragma unroll
-    for (int i = 0; i < DPL / 2; i++) st.L[i] = 0; // first step: L = 0, min = 0 => L = C
-    st.minpk = 0;
+        for (int i = 0; i < NP; i++) st.L[i] = __hip_atomic_load(hp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // min over the pixel's disparities, as the step before would have left it
+        u32 m = st.L[0];
+#pragma unroll
+        for (int i = 1; i < NP; i++) m = pk_min(m, st.L[i]);
+        u32 mm = min(m & 0xFFFFu, m >> 16);
+        mm = grp_min_u32<16>(mm);
+        st.minpk = pk_splat(mm);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; i++) st.L[i] = 0; // first step: L = 0, min = 0 => L = C
+        st.minpk = 0;
+    }
+    const int tb = g0 * DPL; // first step of this piece
     {
-        // the window before the first step: W needs cr[-dbase-(DPL-1) .. -dbase-1] in slots 1..DPL-1, E needs cr[Wp-1-dbase-j] in slot j
-        const int so = 4 * (EAST ? Wp - DPL : -DPL);
+        // the window before step tb: W needs cr[x-dbase-(DPL-1) .. x-dbase-1] (x = tb) in slots 1..DPL-1, E needs cr[x-dbase-j] (x = Wp-1-tb) in slot j
+        const int so = 4 * (EAST ? Wp - DPL - tb : tb - DPL);
         u32 blk[DPL];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
@@ -1089,42 +1173,90 @@ __device__ __forceinline__ void we12_line(const We12Args &a, const u32 *s_lut, c
         for (int m = 0; m < DPL; m++) st.r[m] = EAST ? blk[DPL - 1 - m] : blk[m];
     }
 #pragma unroll
-    for (int q = 0; q < AHEAD; q++) we12_load_quad<EAST, DPL>(st.T[q], ln, q < nquads ? q : nquads - 1, Wp);
+    for (int q = 0; q < AHEAD; q++) we12_load_quad<EAST, DPL>(st.T[q], ln, tb / 4 + q < nquads ? tb / 4 + q : nquads - 1, Wp);
+    if (LQ == 1) we12_load_left_quad<EAST, DPL>(st.CLq[0], st.Gq[0], ln, tb / 4, Wp);
+    if (LQ != 1) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int ta = i < Wp ? i : Wp - 1;
-        const int xa = EAST ? Wp - 1 - ta : ta;
-        st.CL[i] = __builtin_amdgcn_raw_buffer_load_b32(ln.cl, ln.cl_off, 4 * xa, 0);
-        st.GI[i] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
+        for (int i = 0; i < 4; i++) {
+            const int ta = tb + i < Wp ? tb + i : Wp - 1;
+            const int xa = EAST ? Wp - 1 - ta : ta;
+            st.CL[i] = __builtin_amdgcn_raw_buffer_load_b32(ln.cl, ln.cl_off, 4 * xa, 0);
+            if (LQ == 0) st.GI[i] = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, xa, 0);
+        }
     }
-    st.prevI = st.GI[0];
-    for (int t0 = 0; t0 < Wp; t0 += DPL) {
+    // the gray value of the step before: the line's first pixel has none, |dI| = 0 there (and L = C whatever P2)
+    if (tb == 0) st.prevI = LQ == 0 ? st.GI[0] : __builtin_amdgcn_ubfe(st.Gq[0], EAST ? 24 : 0, 8);
+    else st.prevI = (u32)__builtin_amdgcn_raw_buffer_load_b8(ln.gray, ln.gray_off, EAST ? Wp - tb : tb - 1, 0);
+    const int te = g1 * DPL < Wp ? g1 * DPL : Wp;
+    for (int t0 = tb; t0 < te; t0 += DPL) {
         // any step of this group in the first D-1 columns?  (W: at the start of the line, E: at its end)
         const bool masked = EAST ? (Wp - 1 - (t0 + DPL - 1) < D - 1) : (t0 < D - 1);
-        we12_steps<EAST, DPL, 0, DPL>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+        we12_steps<EAST, DPL, 0, DPL, LQ>(st, s_lut, ln, t0, Wp, P1pk, masked, nquads);
+    }
+    if (te < Wp && !(a.serial & 0x10000000u)) { // the next piece of this line continues from here (tests mute this: We12Args)
+        u32 *hp = hand_out + (threadIdx.x & 63) * NP;
+#pragma unroll
+        for (int i = 0; i < NP; i++) __hip_atomic_store(hp + i, st.L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is in the XCD's L2 before the flag goes out
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, (a.serial << 4) | (u32)(piece + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 #ifndef WE12_WPB
 #define WE12_WPB 1 // waves per block (1: 0.875 ms per 16 frames, 4: 0.90 -- single-wave blocks spread more evenly over the SIMDs)
 #endif
-template <int DPL>
+template <int DPL, int LQ>
 __global__ void __launch_bounds__(64 * WE12_WPB) sgm_we12_kernel(We12Args a)
 {
     constexpr int D = 16 * DPL;
     __shared__ u32 s_lut[256];
+#ifdef VPPX_EXPERIMENT
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int i = threadIdx.x; i < 256; i += 64 * WE12_WPB) s_lut[i] = pk_splat(a.p2lut[i]);
     __syncthreads();
-    // blockIdx.x enumerates (row block, direction, frame); XCD-aware like sgm_paths_kernel: frame f -> XCD f % 8
+    // blocks [0, n_whole) run a line quad each; the blocks behind them a piece of one of the remaining ("tail") line quads
+    // `lead` blocks come first and leave at once: one per CU.  A CU hands its waves to its SIMDs in a fixed cycle (0, 2, 1, 3), but
+    // the FIRST wave it receives after another kernel lands off that cycle (tools/we_trace.py --order: one SIMD of a fifth of the
+    // CUs ends up with 5 whole lines and another with 3), which only matters once the launch is cut to fill every SIMD alike.
+    int unit = (int)blockIdx.x - a.lead, piece = 0;
+    if (unit < 0) return;
+    const int ngroups = (a.Wp + DPL - 1) / DPL; // (the last group of a line may be a part of one)
+    int g0 = 0, g1 = ngroups;
+    const u32 *hand_in = nullptr;
+    u32 *hand_out = nullptr, *flag = nullptr;
+    if (a.pieces > 1 && unit >= a.n_whole) {
+        // Behind the whole lines (and a few blocks that only bring the count to a multiple of 8): piece j of tail line i is block
+        // tail_base + j * tail_pitch + i, tail_pitch a multiple of 8 -- all pieces of a line on one XCD, piece j dispatched before
+        // piece j + 1.
+        if (unit < a.tail_base) return;
+        const int k = unit - a.tail_base, tail = k % a.tail_pitch;
+        piece = k / a.tail_pitch;
+        if (tail >= a.ntail) return;
+        // The pieces are a chain: each must finish before the next can start, so they go first on their SIMDs.  (The issue
+        // arbiter takes the oldest wave among equals and these, the last blocks of the grid, are the youngest: without the
+        // priority the first piece of a 16-frame launch finished after 615 us of 875, tools/we_trace.py.)
+        __builtin_amdgcn_s_setprio(3);
+        unit = a.n_whole + tail;
+        g0 = piece * a.piece_groups;
+        g1 = piece == a.pieces - 1 ? ngroups : g0 + a.piece_groups;
+        // records and flags per line quad, i.e. per wave of the block: [tail block][wave][piece boundary][64 lanes][DPL / 2]
+        const int wv = WE12_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tl = tail * WE12_WPB + wv;
+        u32 *rec = a.hand + ((size_t)tl * (a.pieces - 1)) * (64 * (DPL / 2));
+        hand_in = piece > 0 ? rec + (size_t)(piece - 1) * (64 * (DPL / 2)) : nullptr;
+        hand_out = rec + (size_t)piece * (64 * (DPL / 2)); // (the last piece never writes)
+        flag = a.hand + (size_t)a.ntail * WE12_WPB * (a.pieces - 1) * (64 * (DPL / 2)) + tl;
+    }
+    // `unit` enumerates (row block, direction, frame); XCD-aware like sgm_paths_kernel: frame f -> XCD f % 8
     const int nrb = a.Hp / (4 * WE12_WPB), per_frame = nrb * 2;
     int f, within;
     if (a.B % 8 == 0) {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int id = unit, xcd = id & 7, j = id >> 3;
         f = (j / per_frame) * 8 + xcd;
         within = j % per_frame;
     } else {
-        f = blockIdx.x / per_frame;
-        within = blockIdx.x % per_frame;
+        f = unit / per_frame;
+        within = unit % per_frame;
     }
     const int east = within / nrb, rb = within % nrb;
     const int y = rb * (4 * WE12_WPB) + (int)(threadIdx.x >> 4);
@@ -1145,8 +1277,18 @@ __global__ void __launch_bounds__(64 * WE12_WPB) sgm_we12_kernel(We12Args a)
     ln.gray_off = rowoff;
     ln.out_off = rowoff * D + ln.dbase;
     const u32 P1pk = pk_splat((u32)a.p1);
-    if (east) we12_line<true, DPL>(a, s_lut, ln, P1pk);
-    else we12_line<false, DPL>(a, s_lut, ln, P1pk);
+    if (east) we12_line<true, DPL, LQ>(a, s_lut, ln, P1pk, g0, g1, piece, hand_in, hand_out, flag);
+    else we12_line<false, DPL, LQ>(a, s_lut, ln, P1pk, g0, g1, piece, hand_in, hand_out, flag);
+#ifdef VPPX_EXPERIMENT
+    if (a.trace && threadIdx.x == 0) {
+        u32 hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[3 * (size_t)blockIdx.x] = trace_t0;
+        a.trace[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        a.trace[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)(xcc & 0xFu) << 32) | hw;
+    }
+#endif
 }
 
 static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gray, const u32 *cl, const u32 *cr, const u16 *p2lut, int p1,
@@ -1157,11 +1299,96 @@ static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gr
     a.Hp = Hp; a.Wp = Wp; a.B = B;
     a.p1 = p1 < 0 ? 0 : (p1 > 231 ? 231 : p1); // exact for P1 >= P2max (see rsgm_launch_paths)
     a.vol_elems = (size_t)B * Hp * Wp * D;
-    const dim3 grid((unsigned)(B * 2 * (Hp / (4 * WE12_WPB))));
-    if (D == 128) sgm_we12_kernel<8><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);
-    else if (D == 192) sgm_we12_kernel<12><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);
-    else sgm_we12_kernel<16><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);
+    // ---- the last layer of waves, cut into pieces (We12Args; VPPX_VARIANT=we_whole keeps every line whole)
+    const int nunits = B * 2 * (Hp / (4 * WE12_WPB)), dpl = D / 16, ngroups = (Wp + dpl - 1) / dpl;
+    a.hand = nullptr; a.n_whole = nunits; a.pieces = 1; a.piece_groups = ngroups; a.serial = 0; a.timeout_ticks = 0;
+    a.ntail = 0; a.tail_base = nunits; a.tail_pitch = 8; a.lead = 0;
+    {
+        static int nsimd_of[VPPX_MAX_DEVICES] = {};
+        const int dv = ctx->device & (VPPX_MAX_DEVICES - 1);
+        if (!nsimd_of[dv]) {
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || ncu <= 0) ncu = 256;
+            nsimd_of[dv] = 4 * ncu;
+        }
+        // (in blocks of WE12_WPB waves: a layer is one wave per SIMD; "we_layer=N": tests cut small launches)
+        const int nsimd = ctx->knobs.we_layer > 0 ? ctx->knobs.we_layer : nsimd_of[dv] / WE12_WPB, tail = nunits % nsimd;
+        // With c pieces per tail line the busiest SIMD carries ceil(tail * c / nsimd) pieces of 1 / c line each, where an uncut tail
+        // costs a whole line: the c in 2..8 (4 bits of the flag count the pieces) with the smallest such load, if that saves at least
+        // a tenth of a line.  Only behind a whole layer: the pieces' chain needs the other waves' work to hide in.
+        // (the pieces of a line hand over through ONE XCD's L2: only where block ids were seen to go round-robin over 8 XCDs)
+        // and only where the launch has the chip to itself: next to a lock-step launch the pieces' priority costs that kernel more than
+        // the cut saves (8 frames of 540x960x192: W/E 1.19 -> 0.90 ms, the lock-step launch 1.21 -> 1.32, the call 2.15 -> 2.24)
+        if (ctx->knobs.we_split && !ctx->capturing && !ctx->we_beside_vert && ctx->vert3_probed && ctx->v3.ok && nunits > nsimd && tail > 0) {
+            int pieces = 1;
+            double best = 0.9;
+            for (int c = 2; c <= 8 && c <= ngroups; c++) {
+                const double load = (double)(((long long)tail * c + nsimd - 1) / nsimd) / c;
+                if (load < best - 1e-9) { best = load; pieces = c; }
+            }
+            if (pieces > 1) {
+                const size_t rec_dwords = ((size_t)tail * (pieces - 1) * (64 * (dpl / 2)) + tail) * WE12_WPB;
+                u32 *hand;
+                int rc = ws_get(ctx, WS_WE_HAND, rec_dwords, &hand);
+                if (rc) return rc;
+                if (ctx->we_hand_seen != (void *)hand || ctx->we_hand_cap != ctx->ws[WS_WE_HAND].cap) {
+                    // fresh memory may hold anything -- for instance the flags of another context's launch with the same serial
+                    // (a wrong frame in a full-size test, once in a few runs): cleared once, then only this context's serials live here
+                    VPPX_HIP(hipMemsetAsync(hand, 0, ctx->ws[WS_WE_HAND].cap, ctx->stream));
+                    ctx->we_hand_seen = (void *)hand;
+                    ctx->we_hand_cap = ctx->ws[WS_WE_HAND].cap;
+                }
+                a.hand = hand; a.n_whole = nunits - tail; a.pieces = pieces; a.piece_groups = ngroups / pieces;
+                a.ntail = tail; a.tail_base = (a.n_whole + 7) & ~7; a.tail_pitch = (tail + 7) & ~7;
+                a.lead = ctx->knobs.we_layer > 0 ? 8 : nsimd_of[dv] / 4; // one per CU
+                a.serial = (++ctx->we_serial) & 0x0FFFFFFFu;
+                if (a.serial == 0) a.serial = (++ctx->we_serial) & 0x0FFFFFFFu;
+                a.timeout_ticks = 20LL * 100000LL; // 20 ms of the 100 MHz wall clock: a whole W/E launch takes 1-3
+                if (ctx->knobs.we_mute) { // tests: no piece passes its state on, every later piece gives up after 0.2 ms and computes its line from the start
+                    a.timeout_ticks = 20000LL;
+                    a.serial |= 0x10000000u; // (readers look for the serial without this bit)
+                }
+            }
+        }
+    }
+    const dim3 grid((unsigned)(a.pieces > 1 ? a.lead + a.tail_base + a.pieces * a.tail_pitch : nunits));
+#ifdef VPPX_EXPERIMENT
+    a.trace = nullptr;
+    const char *trace_path = getenv("VPPX_EXP_WE_TRACE"); // (experiment builds read their hooks where they act)
+    if (trace_path && !ctx->capturing) {
+        u64 *tr;
+        int rc = ws_get(ctx, WS_WE_TRACE, (size_t)3 * grid.x, &tr);
+        if (rc) return rc;
+        a.trace = (unsigned long long *)tr;
+        VPPX_HIP(hipMemsetAsync(tr, 0, (size_t)3 * grid.x * 8, ctx->stream)); // (blocks that only pad the grid leave zeros)
+    }
+#endif
+    // how the left view's operands are loaded (bit-identical): next to a lock-step launch fewer memory instructions count;
+    // alone on the chip the per-step loads are what was measured faster (NOTEBOOK, round 6).  VPPX_VARIANT=we_lq0 / we_lq1 force one.
+    const int lq = ctx->knobs.we_lq >= 0 ? ctx->knobs.we_lq : (ctx->we_beside_vert ? 1 : 0);
+#define WE12_LAUNCH(DPL)                                                                                      \
+    do {                                                                                                      \
+        if (lq == 1) sgm_we12_kernel<DPL, 1><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);                     \
+        else sgm_we12_kernel<DPL, 0><<<grid, 64 * WE12_WPB, 0, ctx->stream>>>(a);                             \
+    } while (0)
+    if (D == 128) WE12_LAUNCH(8);
+    else if (D == 192) WE12_LAUNCH(12);
+    else WE12_LAUNCH(16);
+#undef WE12_LAUNCH
     VPPX_CHECK_LAUNCH();
+#ifdef VPPX_EXPERIMENT
+    if (a.trace) { // the last launch's trace, every time: (grid, n_whole, pieces, tail_base, tail_pitch, ntail), then 3 words per block
+        std::vector<unsigned long long> h((size_t)3 * grid.x + 6);
+        VPPX_HIP(hipMemcpyAsync(h.data() + 6, a.trace, (size_t)3 * grid.x * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VPPX_HIP(hipStreamSynchronize(ctx->stream));
+        h[0] = grid.x; h[1] = (unsigned long long)a.n_whole; h[2] = (unsigned long long)a.pieces;
+        h[3] = (unsigned long long)(a.lead + a.tail_base); h[4] = (unsigned long long)a.tail_pitch; h[5] = (unsigned long long)a.ntail;
+        if (FILE *f = fopen(trace_path, "wb")) {
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     return 0;
 }
 

@@ -170,6 +170,14 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
             if (has("sum_trap0")) ctx->knobs.sum_trap = 0;
             if (has("sum_trap1")) ctx->knobs.sum_trap = 1;
             if (has("we_after")) ctx->knobs.we_next = 0;
+            if (has("we_whole")) ctx->knobs.we_split = 0;
+            if (has("we_mute")) ctx->knobs.we_mute = 1;
+            {
+                const size_t wl = v.find("we_layer=");
+                if (wl != std::string::npos) ctx->knobs.we_layer = atoi(v.c_str() + wl + 9);
+            }
+            if (has("we_lq0")) ctx->knobs.we_lq = 0;
+            if (has("we_lq1")) ctx->knobs.we_lq = 1;
 #ifdef VPPX_EXPERIMENT
             if (has("pipe_mid")) ctx->pipe_mid = true; // the next front stage starts behind the vertical kernel, next to W/E (measured: 9.16 -> 9.6 ms per step)
             const size_t sb = v.find("sum_blocks=");
@@ -740,7 +748,9 @@ static int run_aggregation(vppx_ctx *ctx, const VppxRsgmParams &p, const RsgmGeo
                 VPPX_HIP(hipEventRecord(ctx->ev_fork, st));
                 VPPX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
                 ctx->stream = ctx->stream2;
+                ctx->we_beside_vert = true;
                 r = launch_we();
+                ctx->we_beside_vert = false;
                 ctx->stream = st;
                 if (r) return r;
                 VPPX_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));

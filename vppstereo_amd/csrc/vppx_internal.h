@@ -90,6 +90,8 @@ enum WsSlot {
     WS_VSTATE,
     WS_VMIN,
     WS_V3ERR,        // device-side copy of the fused kernel's error word (void_if_lost_kernel)
+    WS_WE_TRACE,     // experiment builds: per-block wall-clock trace of the W/E kernel
+    WS_WE_HAND,      // W/E kernel: path states handed from piece to piece of the split tail lines + a flag per line (We12Args)
     WS_DSI,          // materialised cost volume (stage API only)
     WS_DISP_L0,
     WS_DISP_L1,
@@ -148,11 +150,19 @@ struct vppx_ctx {
         int sum_gl8 = 0;      // "sum_gl8": 8 lanes per pixel in the fused sum / WTA kernel (D = 128 / 192)
         int sum_trap = 2;     // D = 256, fused layout: trapezoid ring with spare slots; "sum_trap1": without them; "sum_trap0": uniform ring, 32-pixel rounds
         int we_next = 1;      // W/E next to an under-filled lock-step launch (rsgm_vert3_plan); "we_after": always behind it
+        int we_split = 1;     // W/E kernel: the lines of the last, part-filled layer of waves are cut into pieces; "we_whole": every line whole
+        int we_layer = 0;     // "we_layer=N" (tests): the W/E launcher takes a layer of waves to be N instead of the device's SIMD count
+        int we_mute = 0;      // "we_mute" (tests): pieces do not publish their state: every later piece takes the give-up path
+        int we_lq = -1;       // "we_lq0" / "we_lq1": the W/E kernel's left-view operand loads (per step / per quad of steps); default by launch
         int sum_blocks = 0;   // (experiment builds) "sum_blocks=N": forced number of blocks of the sum / WTA kernel
     } knobs;
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
     int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
     int last_parts = 1;            // parts the last fused call ran as (vppx_last_call_parts)
+    unsigned we_serial = 0;        // launch serial of the W/E kernel's hand-off flags
+    void *we_hand_seen = nullptr;  // the hand-off buffer as it was last cleared (launch_we12)
+    size_t we_hand_cap = 0;
+    bool we_beside_vert = false;   // the W/E launch being queued runs next to a lock-step launch (run_aggregation)
     unsigned long long *draws_dst = nullptr; // device [B]: where the fused call leaves every frame's draw count (set per call by a frame stream)
     int last_sum_nvol = 0;         // volumes the last fused sum / WTA launch added (4: fused layout, 8: eight paths) and its
     int last_sum_D = 0, last_sum_B = 0; // shape: what a pipelined front stage has to fit next to (vpp_rsgm_one)
