@@ -1,4 +1,5 @@
-"""tools/soak_shapes.py [steps]: the pipelined loop with the occlusion mask at shapes that take the round-5 code paths -- 20 frames of
+"""tools/soak_shapes.py [steps]: the pipelined loop with the occlusion mask at shapes that take the round-5 / round-6 code paths -- 32 and 12 frames of
+540x960x192 (W/E with its last layer of waves cut into pieces), 20 frames of
 540x960x192 (a whole lock-step round + 4: two lock-step launches, W/E next to the second), 16 frames of 375x1242x192 (12 + 4),
 8 frames of 540x960x192 (W/E next to an under-filled launch), 8 frames of 1536x2048x256 (trapezoid ring) -- for `steps` back-to-back
 steps each, every tenth result compared with the first and with the 8-path layout; prints ms per step and mismatches."""
@@ -16,7 +17,9 @@ eng = Engine()
 eng.set_pipeline(True)
 dev = eng.device
 total_bad = 0
-for (B, H, W, D, p) in ((20, 540, 960, 192, 0.03), (16, 375, 1242, 192, 0.05), (8, 540, 960, 192, 0.03), (8, 1536, 2048, 256, 0.01)):
+# (round 6: 32 and 12 frames of 540x960x192 run their W/E launches with the last layer of waves cut into 4 / 5 dependent pieces)
+for (B, H, W, D, p) in ((32, 540, 960, 192, 0.03), (12, 540, 960, 192, 0.03), (20, 540, 960, 192, 0.03), (16, 375, 1242, 192, 0.05), (8, 540, 960, 192, 0.03),
+                        (8, 1536, 2048, 256, 0.01)):
     nu = min(B, 4)
     b = synth.make_batch(nu, H, W, D, p, seed=B + H)
     idx = [i % nu for i in range(B)]
