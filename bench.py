@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 AGG_BYTES_PER_CELL = 10.0        # aggregation share of the 16 B/cell algorithmic bytes
 PATH_BYTES_PER_CELL = 16.0       # whole path, + 50 B/pixel
 PATH_BYTES_PER_PIXEL = 50.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06_pmc.json")
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
 # average issue cost of one VALU wave-instruction of the FUSED VERTICAL kernel's row loop (and of no other kernel: it is only
 # applied to the dominant kernel's own instruction count): its mix of full-rate (~2.5 cycles) and half-rate (~4 cycles:
