@@ -413,7 +413,7 @@ const char *vppx_stage_name(int i);
 
 /* ---- environment ------------------------------------------------------------------------------
  * Every variable the shipped library reads, all of them ONCE, in vppx_create (nothing else calls getenv; `tools/build_exp.sh`
- * measurement builds add VPPX_V3_IGNORE_LOST and VPPX_EXP_*, tools/ only):
+ * measurement builds add VPPX_V3_IGNORE_LOST, VPPX_EXP_WE_TRACE and the other VPPX_EXP_*, tools/ only):
  *   VPPX_VERT           aggregation layout: -1 / unset = by shape, 0 = eight line-parallel paths, 3 = fused layout whenever the
  *                       shape allows it, 1 = the round-1 band-marching kernel (vppx_uses_vert)
  *   VPPX_CHUNK          parts of a fused call: unset = one round of the lock-step kernel each, 0 = whole batches, n = n frames

@@ -1354,7 +1354,7 @@ static int launch_we12(vppx_ctx *ctx, int B, int Hp, int Wp, int D, const u8 *gr
     const dim3 grid((unsigned)(a.pieces > 1 ? a.lead + a.tail_base + a.pieces * a.tail_pitch : nunits));
 #ifdef VPPX_EXPERIMENT
     a.trace = nullptr;
-    const char *trace_path = getenv("VPPX_EXP_WE_TRACE"); // (experiment builds read their hooks where they act)
+    const char *trace_path = ctx->exp_we_trace.empty() ? nullptr : ctx->exp_we_trace.c_str(); // VPPX_EXP_WE_TRACE (vppx_create)
     if (trace_path && !ctx->capturing) {
         u64 *tr;
         int rc = ws_get(ctx, WS_WE_TRACE, (size_t)3 * grid.x, &tr);

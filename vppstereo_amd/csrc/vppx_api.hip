@@ -195,6 +195,8 @@ extern "C" int vppx_create(vppx_ctx **out, int device)
 #ifdef VPPX_EXPERIMENT // measurement builds only (tools/build_exp.sh): the shipped library cannot be told to ignore a lost lock step
         e = getenv("VPPX_V3_IGNORE_LOST");
         if (e && atoi(e) > 0) ctx->v3.ignore_lost = true;
+        e = getenv("VPPX_EXP_WE_TRACE");
+        if (e && *e) ctx->exp_we_trace = e;
 #endif
         e = getenv("VPPX_V3_SPIN_LIMIT");
         if (e && atoi(e) > 0) ctx->v3.spin_limit = (unsigned)atoi(e);

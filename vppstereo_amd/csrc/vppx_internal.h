@@ -159,6 +159,9 @@ struct vppx_ctx {
     int use_vert = -1;             // VPPX_VERT: -1 pick by shape (default), 0 eight line-parallel paths, 1 band marching, 3 fused vertical kernel
     int last_vert = 0;             // what the last aggregation used (vppx_uses_vert)
     int last_parts = 1;            // parts the last fused call ran as (vppx_last_call_parts)
+#ifdef VPPX_EXPERIMENT
+    std::string exp_we_trace;      // VPPX_EXP_WE_TRACE: file the W/E kernel's per-block trace of the last launch goes to (tools/we_trace.py)
+#endif
     unsigned we_serial = 0;        // launch serial of the W/E kernel's hand-off flags
     void *we_hand_seen = nullptr;  // the hand-off buffer as it was last cleared (launch_we12)
     size_t we_hand_cap = 0;
