@@ -161,3 +161,29 @@ def test_stream_reruns_batches_after_a_lost_lock_step():
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert np.array_equal(a, b) and not np.isnan(a).any()
+
+
+def test_full_size_stream_in_whole_lock_step_rounds_against_the_oracle():
+    """26 frames of 540 x 960 x 192 with the default batch (one round of the lock-step kernel: 16 here), occlusion mask on the way: the
+    batches take the fused layout with the cut W/E launch, upload / kernels / download of consecutive batches overlap -- and frames 0,
+    15, 16 and 25 (first and last of each batch) equal the CPU oracle, every frame its draw count."""
+    from vppstereo_amd.pipeline import FrameStream
+    H, W, D, seed = 540, 960, 192, 3
+    pool = _frames(4, H, W, D, 0.03, 40)
+    frames = [pool[(3 * i) % 4] for i in range(26)]
+    got, draws = [], []
+    with FrameStream(H, W, 3, seed=seed, maskocc=True, rsgm_kw=dict(dmax=D)) as fs:
+        assert fs.batch == 16
+        for r in fs.run(iter(frames)):
+            got.append(r)
+            draws.append(fs.last_draws)
+        assert fs.counts() == (26, 0, 0, 0)
+    assert len(got) == 26
+    for f in (0, 15, 16, 25):
+        l, r, h = frames[f]
+        conf = oracle.occlusion_heuristic(h)[1]
+        oracle.init_rand(seed + f)
+        lo, ro = oracle.vpp(l, r, h, g_occ=conf)
+        assert np.array_equal(got[f], oracle.compute_rsgm(l, lo, ro, dmax=D)), f
+    # the same scene at another position of the stream draws from another seed: different colours, so (almost surely) another map
+    assert not np.array_equal(got[0], got[4]) and draws[0] > 0 and len(set(draws[i] for i in (0, 4, 8))) == 1
