@@ -118,6 +118,10 @@ def test_stream_refuses_what_it_cannot_do_and_reports_a_full_ring():
         FrameStream(32, 64, maskocc=True, with_g_occ=True)
     with pytest.raises(TypeError):
         FrameStream(32, 64, vpp_kw=dict(blendin=0.2))
+    with pytest.raises(Exception, match="dmax % 8"):                      # the hot path's own checks, made when the stream is created
+        FrameStream(32, 64, rsgm_kw=dict(dmax=60))
+    with pytest.raises(Exception, match="too small"):
+        FrameStream(4, 64)
     fr = _frames(1, 32, 64, 64, 0.05, 1)[0]
     with FrameStream(32, 64, batch=2, depth=2, rsgm_kw=dict(dmax=64)) as fs:
         with pytest.raises(ValueError, match="shape"):
@@ -187,3 +191,24 @@ def test_full_size_stream_in_whole_lock_step_rounds_against_the_oracle():
         assert np.array_equal(got[f], oracle.compute_rsgm(l, lo, ro, dmax=D)), f
     # the same scene at another position of the stream draws from another seed: different colours, so (almost surely) another map
     assert not np.array_equal(got[0], got[4]) and draws[0] > 0 and len(set(draws[i] for i in (0, 4, 8))) == 1
+
+
+def test_stream_with_the_max_distance_method_and_uniform_colours():
+    """The colour method without random draws (vpp_core_opt.pyx:133-341) through the stream: equal to one `run_frame` per frame, draw
+    counts 0; uniform colours with the random method: equal as well, one draw per hint and channel."""
+    from vppstereo_amd.pipeline import FrameStream
+    H, W, D = 40, 104, 64
+    frames = _frames(7, H, W, D, 0.05, 900)
+    for kw in (dict(method="maxDistance", wsize=3), dict(uniform_color=True, wsize=5)):
+        want = _one_by_one(frames, 21, False, dict(kw), dict(dmax=D))
+        got, draws = [], []
+        with FrameStream(H, W, 3, batch=3, seed=21, vpp_kw=dict(kw), rsgm_kw=dict(dmax=D), return_patterns=True) as fs:
+            for r in fs.run(iter(frames)):
+                got.append(r)
+                draws.append(fs.last_draws)
+        for f in range(7):
+            assert np.array_equal(got[f][0], want[f][0]) and np.array_equal(got[f][1], want[f][1]) and np.array_equal(got[f][2], want[f][2]), (kw, f)
+        if kw.get("method") == "maxDistance":
+            assert draws == [0] * 7
+        else:
+            assert draws == [w[4] for w in want]

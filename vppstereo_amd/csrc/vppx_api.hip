@@ -328,6 +328,17 @@ static int lockstep_check(vppx_ctx *ctx)
 }
 
 int vppx_lockstep_check_internal(vppx_ctx *ctx) { return lockstep_check(ctx); } // (vppx_fstream.hip)
+static int check_frames(int B, int H, int W, int C);
+static int check_vpp_params(const VppxVppParams &p);
+static int check_rsgm_params(const VppxRsgmParams &p);
+// the argument checks of the fused entry points, for a frame stream to make when it is CREATED (not at its first full batch)
+int vppx_check_hot_path_args_internal(const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W, int C)
+{
+    int rc;
+    if ((rc = check_frames(B, H, W, C))) return rc;
+    if ((rc = check_vpp_params(*vp))) return rc;
+    return check_rsgm_params(*rp);
+}
 
 extern "C" int vppx_synchronize(vppx_ctx *ctx)
 {

@@ -24,6 +24,7 @@
 #include <thread>
 
 int vppx_lockstep_check_internal(vppx_ctx *ctx); // vppx_api.hip
+int vppx_check_hot_path_args_internal(const VppxVppParams *vp, const VppxRsgmParams *rp, int B, int H, int W, int C);
 
 namespace {
 
@@ -209,6 +210,10 @@ extern "C" int vppx_fstream_create(vppx_ctx *ctx, const VppxOccParams *op, const
     if (ctx->is_child || ctx->nsub > 1 || ctx->graph_mode || ctx->stage_timing || ctx->legacy_stream) {
         vppx_set_error("vppx_fstream_create: the context must launch on a stream of its own, without sub-streams, graph mode or stage timing");
         return VPPX_E_INVALID_ARG;
+    }
+    {
+        const int rc = vppx_check_hot_path_args_internal(vp, rp, batch, H, W, C); // (same codes and messages as the hot path itself)
+        if (rc) return rc;
     }
     DevGuard g(ctx->device);
     vppx_fstream *fs = new vppx_fstream();
