@@ -77,11 +77,15 @@ typedef struct VppxVppParams {
     int32_t use_distance_patch; /*                               [0]                        */
     int32_t use_bilateral_patch;/* gate on |g - filled_g| < 0.1  [0] (needs filled_g)       */
     double distance_gamma;      /*                               [0.3]                      */
-    float dmin, dmax;           /* min / max positive hint of the frame (wrapper :410-411)  */
+    float dmin, dmax;           /* min / max positive hint of the frame (wrapper :410-411); ignored with per_frame_range */
     /* random stream (libc rand() in the reference, vpp_core_opt.pyx:33-35,93,102):
      * frame f of a batch draws from srand(seed + f) starting rand_offset draws in.        */
     uint32_t seed;              /*                               [1]                        */
-    uint32_t reserved0;
+    /* use_distance_patch in a batch: 1 = every frame's dmin / dmax are taken from ITS OWN hints on the device (min / max of the
+     * positive values), which is what vpp() does per call (vpp_standalone.py:410-411); 0 = dmin / dmax above, one pair for the
+     * whole batch.  A frame whose positive hints all have one value -- the reference's _get_patch_size_based_on_distance divides
+     * by zero there -- gets the full patch size.                                    [0]     */
+    uint32_t per_frame_range;
     uint64_t rand_offset;       /*                               [0]                        */
     /* _bilateral_filling (vpp_standalone.py:372-394, wrapper :419-420): when
      * use_bilateral_patch is set and no filled_g is passed, the library densifies the hints
@@ -286,7 +290,7 @@ int vppx_occ_vpp_rsgm_host(vppx_ctx *ctx, const VppxOccParams *op, const VppxVpp
  * consumer thread (the calls release nothing to other threads but do not hold Python's GIL).
  * flags: VPPX_FS_PATTERNS pop can return the patterned pair; VPPX_FS_MASK (with op) the mask; VPPX_FS_GOCC every push brings
  * a caller's mask (op must be NULL).  copy_threads < 0: chosen from the host's core count.
- * use_distance_patch is refused (VPPX_E_UNSUPPORTED): vpp() takes dmin / dmax from each frame's hints. */
+ * use_distance_patch: dmin / dmax are each frame's own, computed on the device (per_frame_range is set for the stream). */
 #define VPPX_FS_PATTERNS 1
 #define VPPX_FS_MASK 2
 #define VPPX_FS_GOCC 4

@@ -112,8 +112,6 @@ def test_stream_results_do_not_depend_on_batch_size_or_copy_threads():
 def test_stream_refuses_what_it_cannot_do_and_reports_a_full_ring():
     from vppstereo_amd import _lib
     from vppstereo_amd.pipeline import FrameStream
-    with pytest.raises(Exception, match="use_distance_patch"):
-        FrameStream(32, 64, vpp_kw=dict(use_distance_patch=True))
     with pytest.raises(ValueError):
         FrameStream(32, 64, maskocc=True, with_g_occ=True)
     with pytest.raises(TypeError):
@@ -212,3 +210,58 @@ def test_stream_with_the_max_distance_method_and_uniform_colours():
             assert draws == [0] * 7
         else:
             assert draws == [w[4] for w in want]
+
+
+@pytest.mark.parametrize("kw", [dict(use_distance_patch=True, wsize=7), dict(use_distance_patch=True, use_bilateral_patch=True, wsize=5, distance_gamma=0.5)])
+def test_stream_with_distance_patches_takes_every_frames_own_hint_range(kw):
+    """`use_distance_patch`: vpp() takes dmin / dmax from the frame's own hints (vpp_standalone.py:410-411); in a batch every frame
+    gets ITS range, computed on the device (VppxVppParams.per_frame_range) -- equal to one `run_frame` per frame, whose host code
+    computes the range the reference's way, and for frame 0 to the oracle.  The frames' ranges differ (scaled hints)."""
+    from vppstereo_amd.pipeline import FrameStream
+    H, W, D = 44, 120, 64
+    frames = []
+    for f, (l, r, h) in enumerate(_frames(9, H, W, D, 0.05, 1200)):
+        frames.append((l, r, (h * np.float32(0.5 + 0.13 * f)).astype(np.float32)))      # another range per frame
+    ranges = {(float(h[h > 0].min()), float(h[h > 0].max())) for _, _, h in frames}
+    assert len(ranges) == 9
+    want = _one_by_one(frames, 5, True, dict(kw), dict(dmax=D))
+    got = []
+    with FrameStream(H, W, 3, batch=4, seed=5, maskocc=True, vpp_kw=dict(kw), rsgm_kw=dict(dmax=D), return_patterns=True) as fs:
+        got = list(fs.run(iter(frames)))
+    for f in range(9):
+        assert np.array_equal(got[f][1], want[f][1]) and np.array_equal(got[f][2], want[f][2]), f
+        assert np.array_equal(got[f][0], want[f][0]) and np.array_equal(got[f][3], want[f][3]), f
+    l, r, h = frames[0]
+    conf = oracle.occlusion_heuristic(h)[1]
+    oracle.init_rand(5)
+    lo, ro = oracle.vpp(l, r, h, g_occ=conf, **kw)
+    assert np.array_equal(lo, got[0][1]) and np.array_equal(ro, got[0][2])
+
+
+def test_batched_engine_call_with_per_frame_range_and_a_single_valued_frame():
+    """The batched device entry point with per_frame_range: frames of different ranges in one call equal their own one-frame calls;
+    a frame whose hints all have ONE value (the reference divides by zero there) gets the full patch size, i.e. equals the same
+    frame without use_distance_patch."""
+    import torch
+    from vppstereo_amd.engine import Engine
+    H, W, D = 36, 88, 64
+    eng = Engine()
+    b = synth.make_batch(4, H, W, D, 0.06, seed=77)
+    hints = b["hints"].copy()
+    hints[1] *= 0.4
+    hints[2] = np.where(hints[2] > 0, np.float32(7.25), np.float32(0))                  # one value only
+    dev = eng.device
+    L, R, Hn = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (b["left"], b["right"], hints))
+    lv, rv = torch.empty_like(L), torch.empty_like(R)
+    eng.vpp_rsgm(L, R, Hn, l_vpp=lv, r_vpp=rv, seed=9, vpp_kw=dict(use_distance_patch=1, per_frame_range=1, wsize=7), rsgm_kw=dict(dmax=D))
+    eng.synchronize()
+    for f in range(4):
+        hf = hints[f]
+        if f == 2:
+            kw = dict(wsize=7)
+        else:
+            kw = dict(use_distance_patch=1, wsize=7, dmin=float(hf[hf > 0].min()), dmax=float(hf[hf > 0].max()))
+        l1, r1 = torch.empty_like(L[f:f + 1]), torch.empty_like(R[f:f + 1])
+        eng.vpp_rsgm(L[f:f + 1], R[f:f + 1], Hn[f:f + 1], l_vpp=l1, r_vpp=r1, seed=9 + f, vpp_kw=kw, rsgm_kw=dict(dmax=D))
+        eng.synchronize()
+        assert torch.equal(l1[0], lv[f]) and torch.equal(r1[0], rv[f]), f

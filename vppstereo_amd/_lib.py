@@ -40,7 +40,7 @@ class VppxVppParams(C.Structure):
         ("direction", C.c_int32), ("uniform_color", C.c_int32), ("discard_occluded", C.c_int32),
         ("interpolate", C.c_int32), ("c", C.c_float), ("c_occ", C.c_float), ("use_distance_patch", C.c_int32),
         ("use_bilateral_patch", C.c_int32), ("distance_gamma", C.c_double), ("dmin", C.c_float), ("dmax", C.c_float),
-        ("seed", C.c_uint32), ("reserved0", C.c_uint32), ("rand_offset", C.c_uint64),
+        ("seed", C.c_uint32), ("per_frame_range", C.c_uint32), ("rand_offset", C.c_uint64),
         ("bilateral_o_xy", C.c_double), ("bilateral_o_i", C.c_double), ("bilateral_th", C.c_double),
     ]
 

@@ -46,6 +46,7 @@ struct VppK {
     int B, H, W, C;
     int n, direction, uniform, discard, interp, use_dist, use_bil;
     float c, c_occ, dmin, dmax;
+    const float2 *range; // use_distance_patch with per_frame_range: [B] {dmin, dmax} of every frame's own hints (hint_range_kernel), else null
     double inv_gamma;
     u8 *l;
     u8 *r;
@@ -72,12 +73,18 @@ struct VppK {
 // ---------------------------------------------------------------------------------------
 // per-hint helpers
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int patch_radius(const VppK &k, float gv)
+__device__ __forceinline__ int patch_radius(const VppK &k, int f, float gv)
 {
     if (!k.use_dist) return k.n;
+    float dmin = k.dmin, dmax = k.dmax;
+    if (k.range) { // the frame's own range, as vpp() takes it per call (vpp_standalone.py:410-411)
+        const float2 r = k.range[f];
+        dmin = r.x; dmax = r.y;
+        if (!(dmax > dmin)) return k.n; // one hint value only: the reference divides by zero there (include/vppx.h)
+    }
     // vpp_standalone.py:7-11 with numba typing: float32 ratio, float64 pow, round half-to-even
-    const float num = __fsub_rn(gv, k.dmin);
-    const float den = __fsub_rn(k.dmax, k.dmin);
+    const float num = __fsub_rn(gv, dmin);
+    const float den = __fsub_rn(dmax, dmin);
     const float ratio = __fdiv_rn(num, den);
     const double gw = pow((double)ratio, k.inv_gamma);
     const double ws = rint(__dadd_rn(__dmul_rn(gw, (double)(2 * k.n)), 1.0)); // patch_size-1 == 2n for odd wsize
@@ -128,6 +135,36 @@ __device__ __forceinline__ int hint_idx(const VppK &k, int f, int y, int x, floa
 // ---------------------------------------------------------------------------------------
 // (one wave per row, four rows per block: the hints of 64 columns are numbered by a ballot and a lane-mask popcount, their
 // draws by one wave scan -- no block barriers; round 3: stage 0.16 -> 0.14 ms per 32 frames, two 50 MB copies included)
+// min / max of a frame's positive hints (vpp_standalone.py:410-411: gt[gt > 0].min() / .max()), one block per frame.  Positive
+// floats order like their bit patterns; NaN and values <= 0 are no hints (vpp_core_opt.pyx:81).  No positive value: {0, 0}, unused.
+__global__ void __launch_bounds__(1024) hint_range_kernel(const float *__restrict__ g, size_t npx, float2 *__restrict__ range)
+{
+    __shared__ u32 s_lo, s_hi;
+    if (threadIdx.x == 0) s_lo = 0xFFFFFFFFu, s_hi = 0u;
+    __syncthreads();
+    const float *gf = g + (size_t)blockIdx.x * npx;
+    u32 lo = 0xFFFFFFFFu, hi = 0u;
+    for (size_t i = threadIdx.x; i < npx; i += 1024) {
+        const float v = gf[i];
+        if (v > 0) {
+            const u32 b = __float_as_uint(v);
+            lo = min(lo, b);
+            hi = max(hi, b);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (u32)__shfl_xor((int)lo, off));
+        hi = max(hi, (u32)__shfl_xor((int)hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_lo, lo);
+        atomicMax(&s_hi, hi);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) range[blockIdx.x] = s_hi == 0u ? make_float2(0.f, 0.f) : make_float2(__uint_as_float(s_lo), __uint_as_float(s_hi));
+}
+
 #define CK_NG 16
 template <bool DIST> // use_distance_patch: the radius of a patch is a float64 pow() of its hint (registers the common case does not pay for)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) compact_kernel(VppK k)
@@ -181,7 +218,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         int nk = 0;
         u32 cnt = 0, drw = 0;
         if (is) {
-            nk = DIST ? patch_radius(k, gv) : k.n;
+            nk = DIST ? patch_radius(k, f, gv) : k.n;
             cnt = (u32)hint_cnt(k, f, y, x, gv, nk);
             drw = k.uniform ? (u32)k.C : (u32)k.C * cnt;
         }
@@ -1812,6 +1849,7 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     k.use_dist = p.use_distance_patch != 0;
     k.use_bil = (p.use_bilateral_patch != 0) && filled_g != nullptr;
     k.c = p.c; k.c_occ = p.c_occ; k.dmin = p.dmin; k.dmax = p.dmax;
+    k.range = nullptr;
     k.inv_gamma = 1.0 / p.distance_gamma;
     k.l = l; k.r = r; k.r_src = r_orig ? r_orig : r; k.g = gmap; k.occ = occ; k.filled = filled_g;
     const size_t npx = (size_t)g.B * g.H * g.W;
@@ -1828,6 +1866,13 @@ int vpp_launch(vppx_ctx *ctx, const VppxVppParams &p, const VppGeom &g, u8 *l, u
     if ((rc = ws_get(ctx, WS_ROW_DRAWS, (size_t)g.B * g.H, &k.row_draws))) return rc;
     if ((rc = ws_get(ctx, WS_ROW_BASE, (size_t)g.B * g.H, &k.row_base))) return rc;
     if ((rc = ws_get(ctx, WS_FRAME_TOT, (size_t)g.B * 2, &k.frame_tot))) return rc;
+    if (k.use_dist && p.per_frame_range) {
+        float2 *range;
+        if ((rc = ws_get(ctx, WS_HINT_RANGE, (size_t)g.B, &range))) return rc;
+        hint_range_kernel<<<dim3(g.B), 1024, 0, ctx->stream>>>(gmap, (size_t)g.H * g.W, range);
+        VPPX_CHECK_LAUNCH();
+        k.range = range;
+    }
     if (p.method == VPPX_METHOD_MAXDIST) {
         if (p.wsize_agg_x < 1 || p.wsize_agg_y < 1) { vppx_set_error("wsize_agg must be >= 1"); return VPPX_E_INVALID_ARG; }
         if ((rc = ws_get(ctx, WS_HINT_X, npx, &k.rng))) return rc;

@@ -112,11 +112,6 @@ extern "C" int vppx_fstream_create(vppx_ctx *ctx, const VppxOccParams *op, const
     }
     if (op && (flags & VPPX_FS_GOCC)) { vppx_set_error("vppx_fstream_create: either the occlusion heuristic (op) or pushed masks (VPPX_FS_GOCC)"); return VPPX_E_INVALID_ARG; }
     if ((flags & VPPX_FS_MASK) && !op) { vppx_set_error("vppx_fstream_create: VPPX_FS_MASK returns the mask of the occlusion heuristic (op is NULL)"); return VPPX_E_INVALID_ARG; }
-    if (vp->use_distance_patch) {
-        // vpp() takes dmin / dmax from each frame's own hints (vpp_standalone.py:403-406); a batch has one pair of them
-        vppx_set_error("vppx_fstream_create: use_distance_patch needs per-frame dmin / dmax; use the one-frame entry point");
-        return VPPX_E_UNSUPPORTED;
-    }
     if (ctx->is_child || ctx->nsub > 1 || ctx->graph_mode || ctx->stage_timing || ctx->legacy_stream) {
         vppx_set_error("vppx_fstream_create: the context must launch on a stream of its own, without sub-streams, graph mode or stage timing");
         return VPPX_E_INVALID_ARG;
@@ -133,6 +128,7 @@ extern "C" int vppx_fstream_create(vppx_ctx *ctx, const VppxOccParams *op, const
     if (op) fs->op = *op;
     fs->vp = *vp;
     fs->vp.rand_offset = 0;
+    fs->vp.per_frame_range = 1; // vpp() takes dmin / dmax from each frame's own hints (vpp_standalone.py:410-411)
     fs->rp = *rp;
     fs->batch = batch; fs->depth = depth; fs->H = H; fs->W = W; fs->C = C; fs->flags = flags;
     fs->px = (size_t)H * W;

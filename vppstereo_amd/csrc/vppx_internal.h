@@ -70,6 +70,7 @@ enum WsSlot {
     WS_ROW_DRAWS,
     WS_ROW_BASE,
     WS_FRAME_TOT,
+    WS_HINT_RANGE,   // [B] {dmin, dmax} of every frame's own hints (use_distance_patch with per_frame_range)
     WS_RAND,
     WS_SEEDS,
     WS_VPP_L,        // scratch copies of the pair (fused path)

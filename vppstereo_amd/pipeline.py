@@ -97,8 +97,8 @@ class FrameStream:
     Frame f (counted from the stream's creation) draws its colours from srand(seed + f): its results equal
     `init_rand(seed + f); run_frame(...)` bit for bit whatever `batch`, wherever a flush falls.  (The reference's single libc
     stream running through all frames is a serial dependency between frames; per-frame streams are what lets frames be
-    batched and sharded)  `use_distance_patch` takes dmin / dmax from each frame's own hints and is
-    refused here: use `run_frame`.  batch=None: one round of the lock-step kernel for this shape (vppx_batch_quantum), else 16.
+    batched and sharded)  `use_distance_patch`: dmin / dmax are each frame's own, computed on the device
+    (a frame whose hints all have ONE value, where the reference divides by zero, gets the full patch size).  batch=None: one round of the lock-step kernel for this shape (vppx_batch_quantum), else 16.
     Results: the float32 disparity map, or with return_patterns (disparity, left_vpp, right_vpp, conf_map or None); each a fresh
     array.  `draws` of the last popped frame (rand() calls it consumed) is in `last_draws`."""
 
