@@ -1808,15 +1808,24 @@ struct Vert3Args {
 // the slot reused must be at least three rows old: a ring of four.
 #define V3_RING 4
 #define V3_TAGMASK 0xFC00FC00u
+#ifndef V3_TAG_BOTH
+#define V3_TAG_BOTH 0
+#endif
+#if V3_TAG_BOTH
+#define V3_TAG_LAST(v, t) ((v) | (t))
+#else
+#define V3_TAG_LAST(v, t) (v)
+#endif
 
 // The edge records of row t-1 (tag word T): group-0 lanes read the left wave's NW record, group-7 lanes the right
 // wave's NE record (a lane reads at most one; lanes without a record read a record of zeros).  Buffer loads with the
 // sc1 bit (device scope: L1 bypassed, served by the XCD's L2) that the compiler can see, so it keeps their results
 // where they land and waits for them where they are used: v3_edges_issue starts them, the straight path's update
 // runs, v3_edges_complete checks the tags, polls again while a record is not there yet, and strips the tags.
-// Tags on the first and the last dword of every 16-byte piece (a lane's aligned 16-byte store and 16-byte load are
-// single requests to one cache line, so a piece is seen whole or not at all; both ends are checked all the same)
-// and on the minimum.
+// A tag on the first dword of every 16-byte piece and on the minimum.  A lane's aligned 16-byte store and 16-byte load are single
+// requests to one cache line: a piece is seen whole or not at all -- until round 6 both ends of a piece were tagged and checked all
+// the same; `tools/tear_bench.hip` then read 6.5e9 pieces (6e8 of them freshly written) through this very store / load pair without
+// one torn piece, while its control -- four dword stores -- tears one piece in a hundred.  -DV3_TAG_BOTH=1 builds the old check.
 template <int NP>
 struct V3Edge {
     u32x4 p[NP / 4]; // the NP pairs in 16-byte pieces
@@ -1842,7 +1851,7 @@ __device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int
     for (;;) {
         u32 bad = r.m ^ T;
 #pragma unroll
-        for (int k = 0; k < NP / 4; k++) bad |= (r.p[k].x ^ T) | (r.p[k].w ^ T);
+        for (int k = 0; k < NP / 4; k++) bad |= V3_TAG_BOTH ? (r.p[k].x ^ T) | (r.p[k].w ^ T) : (r.p[k].x ^ T);
         const bool ok = !want || (bad & V3_TAGMASK) == 0;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         ++spins;
@@ -1864,7 +1873,7 @@ __device__ __forceinline__ void v3_edges_complete(__amdgpu_buffer_rsrc_t xr, int
 #pragma unroll
     for (int k = 0; k < NP / 4; k++) {
         r.p[k].x &= ~V3_TAGMASK;
-        r.p[k].w &= ~V3_TAGMASK;
+        if (V3_TAG_BOTH) r.p[k].w &= ~V3_TAGMASK;
     }
     r.m &= ~V3_TAGMASK;
 }
@@ -2030,14 +2039,14 @@ __global__ void __launch_bounds__(256) sgm_vert3_kernel(Vert3Args a)
         if (t + 1 < Hp && g == 7 && has_right) { // the last pixel's state goes to the right wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (0 * 8 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], L1[i + 3] | Tout};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], V3_TAG_LAST(L1[i + 3], Tout)};
             q[NP] = mn1 | Tout;
         }
         sgm_update_split<NP, 8>(L2, C, P1pk, P2c, mn2, first, last);
         if (t + 1 < Hp && g == 0 && has_left) { // the first pixel's state goes to the left wave
             u32 *q = xb_own + par_out * (2 * 8 * V3_XW) + (1 * 8 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], L2[i + 3] | Tout};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], V3_TAG_LAST(L2[i + 3], Tout)};
             q[NP] = mn2 | Tout;
         }
         __builtin_amdgcn_s_setprio(0);
@@ -2306,7 +2315,7 @@ __global__ void __launch_bounds__(256, 2) sgm_vert4_kernel(Vert3Args a)
         if (t + 1 < Hp && g == 15 && has_right) { // the last pixel's state goes to the right wave
             u32 *q = xb_own + par_out * (2 * 4 * V3_XW) + (0 * 4 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], L1[i + 3] | Tout};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L1[i] | Tout, L1[i + 1], L1[i + 2], V3_TAG_LAST(L1[i + 3], Tout)};
             q[NP] = mn1 | Tout;
         }
         {
@@ -2316,7 +2325,7 @@ __global__ void __launch_bounds__(256, 2) sgm_vert4_kernel(Vert3Args a)
         if (t + 1 < Hp && g == 0 && has_left) { // the first pixel's state goes to the left wave
             u32 *q = xb_own + par_out * (2 * 4 * V3_XW) + (1 * 4 + lg) * V3_XW;
 #pragma unroll
-            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], L2[i + 3] | Tout};
+            for (int i = 0; i < NP; i += 4) *(u32x4 *)(q + i) = u32x4{L2[i] | Tout, L2[i + 1], L2[i + 2], V3_TAG_LAST(L2[i + 3], Tout)};
             q[NP] = mn2 | Tout;
         }
         __builtin_amdgcn_s_setprio(0);
