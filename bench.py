@@ -274,7 +274,7 @@ def cpu_baseline(n_frames, gpu_out=None):
                 sample=f"{n_frames} full {H}x{W}x{D} frames (occlusion heuristic + VPP rnd + rSGM), oracle/liboracle.so "
                        f"gcc {_oracle_flags().split(' -fPIC')[0]}, 1 thread, {t_tot / n_frames:.2f} s/frame, "
                        f"host has {os.cpu_count()} cpus; the port's rSGM is scalar C, about an order of magnitude slower than the "
-                       "SSE rSGM of the literature (SURVEY section 6; `cpu_baseline_simd` is the same port with an AVX2 aggregation): the GPU/CPU ratio is not a kernel-quality figure.  Calibration "
+                       "SSE rSGM of the literature (SURVEY section 6; `cpu_baseline_simd` is the same port with AVX2 aggregation, WTA and median): the GPU/CPU ratio is not a kernel-quality figure.  Calibration "
                        "against the real reference (profiles/r05_cpu_calibration.json, tools/calibrate_cpu.py): the VPP half of the port "
                        "takes 0.49x the time of the reference's Cython scan (5.4 vs 10.9 ms per frame, bit-identical); the rSGM half "
                        "(> 99 % of the time) cannot be calibrated, pyrSGM is not in the reference's tree")
@@ -300,8 +300,9 @@ def cpu_baseline_simd(n_frames, gpu_out=None):
         oracle.set_simd(False)
     return dict(value=n_frames * H * W * D / t_tot / 1e6, unit="Mdisparities/s", cores=1, kind="port", s_per_frame=round(t_tot / n_frames, 3),
                 epe_vs_gpu=epe, flags=_oracle_flags().split(' -fPIC')[0],
-                sample=f"{n_frames} full {H}x{W}x{D} frames, the oracle with its AVX2 aggregation twin (16 disparities per vector; cost, WTA and "
-                       "the Python-glue stages stay scalar C), 1 thread")
+                sample=f"{n_frames} full {H}x{W}x{D} frames, the oracle with its AVX2 twins: aggregation as two raster scans of four paths "
+                       "(16 disparities per vector), left / right WTA (16 pixels per vector), 3x3 median; cost volumes kept between frames; the "
+                       "census, the cost (popcnt) and the glue stages stay scalar C; 1 thread")
 
 
 def cpu_baseline_parallel():
@@ -329,6 +330,67 @@ def cpu_baseline_parallel():
                 sample=f"{n} frames on {n} processes = the host's physical cores ({logical} logical cpus; memory allows {mem_procs} "
                        f"processes), wall {wall:.1f} s (includes frame synthesis), mean {sum(per) / n:.2f} s/frame/core; the port's "
                        "rSGM is scalar C (about an order of magnitude slower than the SSE rSGM of the literature, SURVEY section 6)")
+
+
+_SIMD_BARRIER = None
+
+
+def _cpu_simd_worker(job):
+    """k frames with the AVX2 twins in this process; frames are synthesised and one is computed (the kept cost volumes get their
+    pages) before every process meets at the barrier; returns (start, end) on the system-wide monotonic clock."""
+    f0, k = job
+    import oracle
+    import synth
+    frames = [synth.make_frame(H, W, D, P_HINTS, seed=1234, frame=f0 + i) for i in range(k)]
+    oracle.set_simd(True)
+
+    def one(i):
+        fr = frames[i]
+        oracle.init_rand(1 + f0 + i)
+        occ = None if _CPU_NO_OCC else oracle.occlusion_heuristic(fr["hints"])[1]
+        lv, rv = oracle.vpp(fr["left"], fr["right"], fr["hints"], g_occ=occ)
+        return oracle.compute_rsgm(fr["left"], lv, rv, dmax=D, subpixel=True)
+
+    one(0)
+    _SIMD_BARRIER.wait(900)          # a worker that died before it breaks the barrier for everyone: no hang
+    t0 = time.perf_counter()
+    for i in range(k):
+        one(i)
+    return t0, time.perf_counter()
+
+
+def cpu_baseline_simd_parallel(frames_per_process=4):
+    """The AVX2 port on every physical core at once, one process per core, a few frames each: what the GPU box's whole host does
+    with the kind of code the reference's natives are.  Memory-bound there (a frame moves ~2 GB through a core's caches), so well
+    below cores x `cpu_baseline_simd`."""
+    global _SIMD_BARRIER
+    import multiprocessing as mp
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or logical
+        mem_procs = int(psutil.virtual_memory().available / (0.75 * 2 ** 30))
+    except Exception:  # noqa: BLE001
+        phys, mem_procs = logical, logical
+    try:
+        phys = min(phys, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    n = max(1, min(phys, mem_procs))
+    k = frames_per_process
+    ctx = mp.get_context("fork")
+    _SIMD_BARRIER = ctx.Barrier(n)
+    try:
+        with ctx.Pool(n) as pool:
+            spans = pool.map(_cpu_simd_worker, [(i * k, k) for i in range(n)], chunksize=1)
+    finally:
+        _SIMD_BARRIER = None
+    wall = max(e for _, e in spans) - min(b for b, _ in spans)
+    per = sum(e - b for b, e in spans) / (n * k)
+    return dict(value=n * k * H * W * D / wall / 1e6, unit="Mdisparities/s", cores=n, kind="port", s_per_frame_per_core=round(per, 3),
+                sample=f"{n * k} frames: {k} on each of {n} processes = the host's physical cores ({logical} logical cpus), the oracle with its "
+                       f"AVX2 twins, all processes released together after synthesising their frames and one untimed frame; wall {wall:.2f} s "
+                       "from the first start to the last end")
 
 
 def kernel_source_sha():
@@ -785,6 +847,9 @@ def run_rank(args):
             result["cpu_baseline_simd"] = cpu_baseline_simd(min(args.cpu_frames, n_unique), gpu_out)
             if not args.no_cpu_parallel:
                 result["cpu_baseline_all_cores"] = cpu_baseline_parallel()
+                result["cpu_baseline_simd_all_cores"] = cpu_baseline_simd_parallel()
+                # the ratio worth quoting: one GPU against the box's whole host running the reference's kind of code
+                result["speedup_vs_cpu_simd_all_cores"] = round(value / result["cpu_baseline_simd_all_cores"]["value"], 1)
         else:
             result["cpu_baseline"] = None
         if world == 1 and not args.no_other_configs and not args.shape and not args.uniform_random and not args.graph:

@@ -202,7 +202,7 @@ def aggregate_SSE(img, dsi, dsi_agg, w, h, dmax, p1, p2min, alpha, gamma, path_m
 
 
 def set_simd(on):
-    """compute_rsgm aggregates with the AVX2 twin from here on (bench.py's `cpu_baseline_simd` leg only; off by default)."""
+    """compute_rsgm aggregates and takes its winners with the AVX2 twins from here on (bench.py's `cpu_baseline_simd` leg only; off by default)."""
     lib().rsgmo_set_simd(int(bool(on)))
 
 
@@ -219,20 +219,27 @@ def _guided_dsi(dsi, hints, validhints):
     return out
 
 
-def matchWTA_SSE(dsi, disp, w, h, dmax, uniqueness):
-    lib().rsgmo_match_wta(_p(dsi, C.c_uint16), _f32(disp), int(w), int(h), int(dmax), C.c_float(uniqueness))
+def matchWTA_SSE(dsi, disp, w, h, dmax, uniqueness, simd=False):
+    """simd=True: the AVX2 twin (rsgmo_match_wta_simd), bit-equal; the scalar function is the checker."""
+    if simd:
+        lib().rsgmo_match_wta_simd(_p(dsi, C.c_uint16), _f32(disp), int(w), int(h), int(dmax), C.c_float(uniqueness), 0)
+    else:
+        lib().rsgmo_match_wta(_p(dsi, C.c_uint16), _f32(disp), int(w), int(h), int(dmax), C.c_float(uniqueness))
 
 
-def matchWTARight_SSE(dsi, disp, w, h, dmax, uniqueness):
-    lib().rsgmo_match_wta_right(_p(dsi, C.c_uint16), _f32(disp), int(w), int(h), int(dmax), C.c_float(uniqueness))
+def matchWTARight_SSE(dsi, disp, w, h, dmax, uniqueness, simd=False):
+    if simd:
+        lib().rsgmo_match_wta_simd(_p(dsi, C.c_uint16), _f32(disp), int(w), int(h), int(dmax), C.c_float(uniqueness), 1)
+    else:
+        lib().rsgmo_match_wta_right(_p(dsi, C.c_uint16), _f32(disp), int(w), int(h), int(dmax), C.c_float(uniqueness))
 
 
 def subPixelRefine(dsi, disp, w, h, dmax, method):
     lib().rsgmo_subpixel_refine(_p(dsi, C.c_uint16), _f32(disp), int(w), int(h), int(dmax), int(method))
 
 
-def median3x3_SSE(src, dst, w, h):
-    lib().rsgmo_median3x3(_f32(src), _f32(dst), int(w), int(h))
+def median3x3_SSE(src, dst, w, h, simd=False):
+    (lib().rsgmo_median3x3_simd if simd else lib().rsgmo_median3x3)(_f32(src), _f32(dst), int(w), int(h))
 
 
 def p2_lut(p2min, alpha, gamma):

@@ -77,3 +77,16 @@ def test_scaling_prediction_is_what_design_section_10_states():
     assert abs(rows[8]["ms_per_step"] - 8.25 * 1.04) < 0.01 and abs(rows[2]["ms_per_step"] - 8.25 * (1 + 0.04 / 7)) < 0.01
     assert rows[8]["efficiency"] >= p["near_linear_means_efficiency_at_8_of_at_least"]
     assert rows[2]["efficiency"] > rows[4]["efficiency"] > rows[8]["efficiency"]
+
+
+def test_all_cores_simd_cpu_leg_counts_its_frames_and_times_only_the_compute():
+    """`cpu_baseline_simd_all_cores`: one process per core, released together after their frames exist; the wall clock runs from the
+    first start to the last end and the figure is frames x cells over it."""
+    r = bench.cpu_baseline_simd_parallel(frames_per_process=1)
+    n = r["cores"]
+    assert n >= 1 and r["unit"] == "Mdisparities/s" and r["kind"] == "port"
+    assert f"{n} frames: 1 on each of {n} processes" in r["sample"]
+    per_core = 540 * 960 * 192 / 1e6 / r["s_per_frame_per_core"]
+    assert 0.3 * n * per_core < r["value"] <= 1.05 * n * per_core     # between badly skewed and perfectly parallel
+    import oracle
+    assert not oracle.get_simd()                                         # the parent's checker stays scalar

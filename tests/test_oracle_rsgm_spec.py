@@ -222,6 +222,60 @@ def test_avx2_aggregation_twin_is_bit_equal_to_the_scalar_checker(D):
             assert np.array_equal(a, b), (case, mask)
 
 
+def test_avx2_wta_twin_is_bit_equal_to_the_scalar_checker():
+    """The other half of `cpu_baseline_simd`: left and right winner-take-all with 16 pixels side by side.  Ties (first minimum
+    wins, a second minimum equal to the first), all-65535 vectors, widths below D and not multiples of 8 or 16, every uniqueness
+    branch (ratio test, neighbour below, neighbour above, invalid)."""
+    rng = np.random.default_rng(77)
+    seen = set()
+    for trial in range(120):
+        D = int(rng.choice([8, 16, 24, 48, 64, 192]))
+        w, h = int(rng.integers(1, 70)), int(rng.integers(1, 4))
+        hi = int(rng.choice([3, 50, 65536]))
+        S = rng.integers(0, hi, (h, w, D)).astype(np.uint16)
+        if trial % 7 == 0:
+            S[:] = 65535
+        if trial % 11 == 0:
+            S[:] = rng.integers(65530, 65536, (h, w, D)).astype(np.uint16)
+        u = float(rng.choice([0.95, 1.0, 0.5, 0.0, 0.77]))
+        for fn in (oracle.matchWTA_SSE, oracle.matchWTARight_SSE):
+            a, b = np.full((h, w), 7, np.float32), np.full((h, w), 9, np.float32)
+            fn(S, a, w, h, D, u)
+            fn(S, b, w, h, D, u, simd=True)
+            assert np.array_equal(a, b), (trial, D, w, h, hi, u, fn.__name__)
+            seen.add(bool((a < 0).any()))
+            seen.add(bool((a >= 0).any()))
+    assert seen == {True, False}
+    S = rng.integers(0, 9, (2, 30, 12)).astype(np.uint16)            # D % 8 != 0: the scalar function runs
+    a, b = np.empty((2, 30), np.float32), np.empty((2, 30), np.float32)
+    oracle.matchWTA_SSE(S, a, 30, 2, 12, 0.95)
+    oracle.matchWTA_SSE(S, b, 30, 2, 12, 0.95, simd=True)
+    assert np.array_equal(a, b)
+
+
+def test_avx2_median_twin_and_the_empty_path_mask():
+    rng = np.random.default_rng(12)
+    for t in range(60):
+        h, w = int(rng.integers(1, 12)), int(rng.integers(1, 40))
+        if t % 3 == 0:
+            a = rng.integers(-1, 4, (h, w)).astype(np.float32)                     # ties everywhere
+        elif t % 3 == 1:
+            a = (rng.random((h, w)) * 190).astype(np.float32)
+            a[rng.random((h, w)) < 0.3] = -10                                       # the invalid marker among sub-pixel values
+        else:
+            a = rng.integers(0, 3, (h, w)).astype(np.float32) * 0.5
+        x, y = np.full_like(a, 5), np.full_like(a, 6)
+        oracle.median3x3_SSE(a, x, w, h)
+        oracle.median3x3_SSE(a, y, w, h, simd=True)
+        assert np.array_equal(x, y), (t, h, w)
+    img = rng.integers(0, 256, (4, 9), dtype=np.uint8)
+    dsi = rng.integers(0, 25, (4, 9, 16)).astype(np.uint16)
+    a, b = np.full_like(dsi, 3), np.full_like(dsi, 4)
+    oracle.aggregate_SSE(img, dsi, a, 9, 4, 16, 11, 17, 0.5, 35, path_mask=0)
+    oracle.aggregate_SSE(img, dsi, b, 9, 4, 16, 11, 17, 0.5, 35, path_mask=0, simd=True)
+    assert not a.any() and not b.any()
+
+
 def test_avx2_twin_falls_back_where_it_does_not_apply_and_compute_rsgm_is_unchanged_by_the_flag():
     rng = np.random.default_rng(5)
     h, w, D = 6, 20, 24                                   # D % 16 != 0: the scalar function runs
