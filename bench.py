@@ -305,10 +305,28 @@ def cpu_baseline_simd(n_frames, gpu_out=None):
                        "census, the cost (popcnt) and the glue stages stay scalar C; 1 thread")
 
 
-def cpu_baseline_parallel():
-    """Same port, one frame per process on every physical core of the host (bounded by memory: a process holds the
-    oracle's cost and path volumes, ~0.5 GB)."""
-    import multiprocessing as mp
+def _cgroup_cpu_quota():
+    """CPUs' worth of time this process tree may use per period (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def _usable_cores():
+    """(processes to start, logical cpus, why): the physical cores this process may really run on at once -- affinity mask, the
+    cgroup's CPU quota (the GPU boxes of the pool give a job 16 CPUs' worth of a 128-core host: more processes than that only
+    time-slice), and memory (a process holds the oracle's cost and path volumes, ~0.5 GB)."""
     logical = os.cpu_count() or 1
     try:
         import psutil
@@ -320,15 +338,25 @@ def cpu_baseline_parallel():
         phys = min(phys, len(os.sched_getaffinity(0)))
     except Exception:  # noqa: BLE001
         pass
-    n = max(1, min(phys, mem_procs))
+    quota = _cgroup_cpu_quota()
+    n = max(1, min(phys, mem_procs, int(quota) if quota and quota >= 1 else phys))
+    why = (f"{phys} physical cores in the affinity mask of {logical} logical cpus, cgroup quota "
+           f"{'none' if quota is None else f'{quota:g} cpus'}, memory for {mem_procs} processes")
+    return n, logical, why
+
+
+def cpu_baseline_parallel():
+    """Same port, one frame per process on every core the job may use (`_usable_cores`)."""
+    import multiprocessing as mp
+    n, logical, why = _usable_cores()
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(n) as pool:
         per = pool.map(_cpu_worker, list(range(n)), chunksize=1)
     wall = time.perf_counter() - t0
     return dict(value=n * H * W * D / wall / 1e6, unit="Mdisparities/s", cores=n, kind="port",
-                sample=f"{n} frames on {n} processes = the host's physical cores ({logical} logical cpus; memory allows {mem_procs} "
-                       f"processes), wall {wall:.1f} s (includes frame synthesis), mean {sum(per) / n:.2f} s/frame/core; the port's "
+                sample=f"{n} frames on {n} processes = the cores this job may use ({why}), "
+                       f"wall {wall:.1f} s (includes frame synthesis), mean {sum(per) / n:.2f} s/frame/core; the port's "
                        "rSGM is scalar C (about an order of magnitude slower than the SSE rSGM of the literature, SURVEY section 6)")
 
 
@@ -359,24 +387,12 @@ def _cpu_simd_worker(job):
     return t0, time.perf_counter()
 
 
-def cpu_baseline_simd_parallel(frames_per_process=4):
-    """The AVX2 port on every physical core at once, one process per core, a few frames each: what the GPU box's whole host does
-    with the kind of code the reference's natives are.  Memory-bound there (a frame moves ~2 GB through a core's caches), so well
-    below cores x `cpu_baseline_simd`."""
+def cpu_baseline_simd_parallel(frames_per_process=8):
+    """The AVX2 port on every core the job may use at once, one process per core, a few frames each: what the GPU box's host
+    share does with the kind of code the reference's natives are."""
     global _SIMD_BARRIER
     import multiprocessing as mp
-    logical = os.cpu_count() or 1
-    try:
-        import psutil
-        phys = psutil.cpu_count(logical=False) or logical
-        mem_procs = int(psutil.virtual_memory().available / (0.75 * 2 ** 30))
-    except Exception:  # noqa: BLE001
-        phys, mem_procs = logical, logical
-    try:
-        phys = min(phys, len(os.sched_getaffinity(0)))
-    except Exception:  # noqa: BLE001
-        pass
-    n = max(1, min(phys, mem_procs))
+    n, logical, why = _usable_cores()
     k = frames_per_process
     ctx = mp.get_context("fork")
     _SIMD_BARRIER = ctx.Barrier(n)
@@ -388,7 +404,7 @@ def cpu_baseline_simd_parallel(frames_per_process=4):
     wall = max(e for _, e in spans) - min(b for b, _ in spans)
     per = sum(e - b for b, e in spans) / (n * k)
     return dict(value=n * k * H * W * D / wall / 1e6, unit="Mdisparities/s", cores=n, kind="port", s_per_frame_per_core=round(per, 3),
-                sample=f"{n * k} frames: {k} on each of {n} processes = the host's physical cores ({logical} logical cpus), the oracle with its "
+                sample=f"{n * k} frames: {k} on each of {n} processes = the cores this job may use ({why}), the oracle with its "
                        f"AVX2 twins, all processes released together after synthesising their frames and one untimed frame; wall {wall:.2f} s "
                        "from the first start to the last end")
 
@@ -848,7 +864,7 @@ def run_rank(args):
             if not args.no_cpu_parallel:
                 result["cpu_baseline_all_cores"] = cpu_baseline_parallel()
                 result["cpu_baseline_simd_all_cores"] = cpu_baseline_simd_parallel()
-                # the ratio worth quoting: one GPU against the box's whole host running the reference's kind of code
+                # the ratio worth quoting: one GPU against every host core the job may use, running the reference's kind of code
                 result["speedup_vs_cpu_simd_all_cores"] = round(value / result["cpu_baseline_simd_all_cores"]["value"], 1)
         else:
             result["cpu_baseline"] = None
