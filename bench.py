@@ -909,9 +909,9 @@ def run_rank(args):
                 from tools import host_stream as hs
                 result["host_stream"] = {
                     "what": "pipeline.FrameStream: frames pushed one at a time from pageable numpy arrays, disparities popped one at a time into "
-                            "fresh numpy arrays, in input order; occlusion mask on the way; batches of one lock-step round, depth 2; ms per frame "
+                            "fresh numpy arrays, in input order; occlusion mask on the way; batches of one lock-step round, a ring of three batches (results leave through a copy-out kernel of 8 workgroups behind the NEXT batch's aggregation); ms per frame "
                             "next to pipeline.run_frame (one synchronous call per frame) and the PCIe floor of the bytes that cross",
-                    "runs": [hs.measure(H, W, D, P_HINTS, 192), hs.measure(375, 1242, 192, 0.05, 192)]}
+                    "runs": [hs.measure(H, W, D, P_HINTS, 384), hs.measure(375, 1242, 192, 0.05, 384)]}
             except Exception as e:  # noqa: BLE001  (a measurement next to the headline: its failure must not lose the line)
                 result["host_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(result), flush=True)

@@ -282,7 +282,11 @@ int vppx_occ_vpp_rsgm_host(vppx_ctx *ctx, const VppxOccParams *op, const VppxVpp
  * every frame is copied once, by `copy_threads` threads, into a page-locked ring of `depth` batches; a full batch (`batch`
  * frames, vppx_batch_quantum is a good value) is uploaded on a copy stream under the previous batch's kernels, runs through
  * vppx_occ_vpp_rsgm_dev (op != NULL: the mask of test.py:154 on the way) or vppx_vpp_rsgm_dev with cross-call pipelining,
- * and comes down on a third stream.  Frame f (counted from the stream's creation) draws from srand(vp->seed + f): results
+ * and comes down on a third stream: a copy-out kernel of a few workgroups that stores into the ring (no runtime copy engine:
+ * which one a device -> host hipMemcpyAsync takes differs between runtime versions, and the blit-kernel one disturbs the hot
+ * path).  With depth >= 3 (recommended: 3) a batch's copy-out waits for the NEXT batch's aggregation to finish, so that it
+ * runs beside the sum / WTA kernel and never beside the lock-step launch; the pop, flush or re-run that needs the results
+ * first releases it at once.  With depth 2 it runs right behind the batch's own kernels.  Frame f (counted from the stream's creation) draws from srand(vp->seed + f): results
  * equal one-frame calls with that seed whatever the batch size and wherever a flush falls.  The context must launch on
  * its own stream (the default of vppx_create) and must not be used for other calls while the stream exists.
  * A lost lock step (vppx_status) is handled inside: pop verifies each batch after its download and re-runs what was in

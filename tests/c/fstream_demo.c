@@ -47,7 +47,7 @@ int main(int argc, char **argv)
     vppx_occ_params_default(&op);
     vp.seed = seed;
     rp.dmax = D;
-    CHECK(vppx_fstream_create(ctx, &op, &vp, &rp, batch, 2, H, W, 3, 0, 2, &fs));
+    CHECK(vppx_fstream_create(ctx, &op, &vp, &rp, batch, 3, H, W, 3, 0, 2, &fs)); /* a ring of three batches (include/vppx.h) */
     int popped = 0, got = 0;
     for (int f = 0; f < n; f++) {
         /* the right view is the left one shifted by 5 columns (a plane at disparity 5) plus noise in the low bits; 4 % hints near 5 */
@@ -64,10 +64,10 @@ int main(int argc, char **argv)
             hints[i] = (r >> 24) < 10 ? 4.0f + (float)((r >> 16) & 3) * 0.5f : 0.0f;
         }
         CHECK(vppx_fstream_push(fs, left, right, hints, NULL));
-        /* take what is certainly finished: everything but the last submitted batch (depth 2) */
+        /* keep two batches in flight, take the rest: the oldest batch's copy-out was released when the newest was submitted */
         int64_t unpopped = 0, filling = 0;
         CHECK(vppx_fstream_counts(fs, NULL, &filling, &unpopped, NULL));
-        while (unpopped > batch) {
+        while (unpopped > 2 * batch) {
             CHECK(vppx_fstream_pop(fs, disp, NULL, NULL, NULL, NULL, &got));
             if (!got) break;
             printf("%d %016llx\n", popped++, (unsigned long long)fnv1a(disp, px * sizeof(float)));

@@ -36,8 +36,8 @@ def _one_by_one(frames, seed, maskocc, vpp_kw, rsgm_kw, g_occ=None):
     return want
 
 
-@pytest.mark.parametrize("maskocc", [True, False])
-def test_stream_of_37_frames_equals_37_run_frame_calls(maskocc):
+@pytest.mark.parametrize("maskocc,depth", [(True, 2), (False, 3), (True, 3), (False, 4)])
+def test_stream_of_37_frames_equals_37_run_frame_calls(maskocc, depth):
     """37 frames, batches of 16 (16 + 16 + a flushed 5): every result in input order, equal to the frame's own one-frame
     call with srand(seed + f), including the number of rand() draws it consumed."""
     from vppstereo_amd.pipeline import FrameStream
@@ -46,7 +46,9 @@ def test_stream_of_37_frames_equals_37_run_frame_calls(maskocc):
     kw = dict(wsize=5, blending=0.3, c_occ=0.2)
     want = _one_by_one(frames, seed, maskocc, kw, dict(dmax=D, p1=9))
     got, draws = [], []
-    with FrameStream(H, W, 3, batch=16, depth=2, seed=seed, maskocc=maskocc, vpp_kw=kw, rsgm_kw=dict(dmax=D, p1=9), return_patterns=True) as fs:
+    # (depth 2: every batch's copy-out right behind its kernels; depth >= 3: held back until the next batch's aggregation is enqueued,
+    # released by the pop that needs it when no next batch comes -- the flushed last one here)
+    with FrameStream(H, W, 3, batch=16, depth=depth, seed=seed, maskocc=maskocc, vpp_kw=kw, rsgm_kw=dict(dmax=D, p1=9), return_patterns=True) as fs:
         for r in fs.run(iter(frames)):
             got.append(r)
             draws.append(fs.last_draws)

@@ -10,7 +10,7 @@ import numpy as np
 import synth
 
 
-def measure(H, W, D, p, n_frames, batch=None, depth=2, copy_threads=-1, pool=8, with_run_frame=True):
+def measure(H, W, D, p, n_frames, batch=None, depth=3, copy_threads=-1, pool=8, with_run_frame=True):
     from vppstereo_amd import pipeline
     frames = []
     for f in range(pool):

@@ -10,7 +10,8 @@
 //     hot path is called with the upload's event as its inputs-ready event and with cross-call pipelining on, so the front
 //     stage of batch k+1 starts next to the sum / WTA kernel of batch k as soon as its inputs are there;
 //   * the disparities (and, on request, mask and patterned pair, and the draw counts) come down on a third stream into the
-//     ring, under the kernels of the next batch.
+//     ring, under the kernels of the next batch: by a copy-out kernel of a few workgroups, held back (ring of >= 3 batches)
+//     until the next batch's lock-step aggregation is over (fs_copy_out_kernel, fs_submit).
 // Frame f of the stream (counted from its creation) draws from srand(seed + f), as frame f of any batched call does: results
 // do not depend on the batch size, on flushes or on where a batch boundary falls, and equal one-frame calls with that seed.
 // A lost lock step (vppx_status) never surfaces as wrong disparities: pop verifies every batch after its download and
@@ -41,6 +42,8 @@ struct Slot {
     int nb = 0;            // frames of the batch the slot holds
     uint32_t seed = 0;     // seed of its first frame
     bool submitted = false, verified = false;
+    bool out_pending = false; // the batch's kernels are enqueued, its copy-out is not yet (see fs_submit)
+    bool out_method_rnd = false;
 };
 
 } // namespace
@@ -154,8 +157,15 @@ extern "C" int vppx_fstream_create(vppx_ctx *ctx, const VppxOccParams *op, const
         return e == hipErrorOutOfMemory ? VPPX_E_OOM : VPPX_E_HIP;
     };
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&fs->s_in, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&fs->s_out, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    // The two copy streams are created at the LOWEST priority: the runtime deals streams of one priority onto a pool of four hardware
+    // queues round-robin, and with the context's three streams (and the caller's own) the copy-out stream landed in the queue of the
+    // context's main stream -- every batch's lock-step launch then queued behind the previous batch's copy-out (0.7-1.0 ms per batch,
+    // seen in the kernel trace's Queue_Id column).  Streams of another priority get queues of their own pool, and the copy-out
+    // kernel's waves yield to the hot path's.
+    int prio_least = 0, prio_greatest = 0;
+    if ((e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess) return fail("hipDeviceGetStreamPriorityRange", e);
+    if ((e = hipStreamCreateWithPriority(&fs->s_in, hipStreamNonBlocking, prio_least)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithPriority(&fs->s_out, hipStreamNonBlocking, prio_least)) != hipSuccess) return fail("hipStreamCreate", e);
     for (auto &s : fs->slots) {
         if ((e = hipHostMalloc((void **)&s.h_in, fs->in_bytes, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
         if ((e = hipHostMalloc((void **)&s.h_out, fs->out_bytes, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
@@ -179,6 +189,61 @@ extern "C" int vppx_fstream_create(vppx_ctx *ctx, const VppxOccParams *op, const
 }
 
 extern "C" void vppx_fstream_destroy(vppx_fstream *fs) { fs_free(fs); }
+
+// Results leave the device through a kernel of a few workgroups that stores into the pinned ring (FS_COPY_WGS x 256 lanes, 16 bytes
+// each per trip: ~20 GB/s, a batch in ~2 ms of the ~4 ms the next batch computes).  Why not hipMemcpyAsync: which engine a device ->
+// pinned-host copy takes is the runtime's choice -- SDMA with ROCm 7.2's libamdhip64, a 256-workgroup blit kernel with the 7.0 one a
+// process that imported torch has loaded -- and the blit kernel, saturating PCIe from every CU, stretched whatever front-stage kernel
+// of the next batch ran beside it (pad+gray+census 66 -> 620 us, the batch period 4.1 -> 4.7 ms; tools/d2h_probe.hip,
+// docs/NOTEBOOK.md round 6).  A trickle of few waves keeps few PCIe writes in flight and leaves the CUs to the hot path.
+#ifndef FS_COPY_WGS
+#define FS_COPY_WGS 8
+#endif
+struct FsCopySegs {
+    const uint4 *src[5];
+    uint4 *dst[5];
+    unsigned long long n16[5];
+    int n;
+};
+__global__ void __launch_bounds__(256) fs_copy_out_kernel(FsCopySegs a)
+{
+    for (int s = 0; s < a.n; s++) {
+        const uint4 *__restrict__ src = a.src[s];
+        uint4 *__restrict__ dst = a.dst[s];
+        for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < a.n16[s]; i += (unsigned long long)gridDim.x * 256ull) dst[i] = src[i];
+    }
+}
+
+// Enqueue a submitted batch's copy-out on the copy-out stream: behind the batch's own kernels and, when asked, behind the
+// aggregation of the call enqueued last on the context.
+static int fs_copy_out(vppx_fstream *fs, Slot &s, bool behind_last_aggregation)
+{
+    vppx_ctx *ctx = fs->ctx;
+    const int nb = s.nb;
+    VPPX_HIP(hipStreamWaitEvent(fs->s_out, s.ev_done, 0));
+    if (behind_last_aggregation) VPPX_HIP(hipStreamWaitEvent(fs->s_out, ctx->ev_agg_done, 0));
+    // segments start on 256-byte boundaries of both buffers (same layout) and are padded to them: whole 16-byte pieces
+    FsCopySegs a;
+    a.n = 0;
+    auto seg = [&](size_t off, size_t bytes) {
+        a.src[a.n] = (const uint4 *)(s.d_out + off);
+        a.dst[a.n] = (uint4 *)(s.h_out + off);
+        a.n16[a.n] = (bytes + 15) / 16;
+        a.n++;
+    };
+    seg(fs->o_disp, fs->px * 4 * nb);
+    if (fs->flags & VPPX_FS_PATTERNS) {
+        seg(fs->o_lv, fs->img * nb);
+        seg(fs->o_rv, fs->img * nb);
+    }
+    if (fs->flags & VPPX_FS_MASK) seg(fs->o_conf, fs->px * nb);
+    if (s.out_method_rnd) seg(fs->o_draws, (size_t)8 * nb);
+    fs_copy_out_kernel<<<FS_COPY_WGS, 256, 0, fs->s_out>>>(a);
+    VPPX_HIP(hipGetLastError());
+    VPPX_HIP(hipEventRecord(s.ev_out, fs->s_out));
+    s.out_pending = false;
+    return 0;
+}
 
 // One batch through the hot path: upload (unless the inputs are still on the device: a re-run), kernels, download.
 static int fs_submit(vppx_fstream *fs, Slot &s, bool upload)
@@ -217,17 +282,19 @@ static int fs_submit(vppx_fstream *fs, Slot &s, bool upload)
     ctx->draws_dst = nullptr;
     if (rc) return rc;
     VPPX_HIP(hipEventRecord(s.ev_done, ctx->stream));
-    VPPX_HIP(hipStreamWaitEvent(fs->s_out, s.ev_done, 0));
-    VPPX_HIP(hipMemcpyAsync(s.h_out + fs->o_disp, s.d_out + fs->o_disp, fs->px * 4 * nb, hipMemcpyDeviceToHost, fs->s_out));
-    if (fs->flags & VPPX_FS_PATTERNS) {
-        VPPX_HIP(hipMemcpyAsync(s.h_out + fs->o_lv, s.d_out + fs->o_lv, fs->img * nb, hipMemcpyDeviceToHost, fs->s_out));
-        VPPX_HIP(hipMemcpyAsync(s.h_out + fs->o_rv, s.d_out + fs->o_rv, fs->img * nb, hipMemcpyDeviceToHost, fs->s_out));
-    }
-    if (fs->flags & VPPX_FS_MASK)
-        VPPX_HIP(hipMemcpyAsync(s.h_out + fs->o_conf, s.d_out + fs->o_conf, fs->px * nb, hipMemcpyDeviceToHost, fs->s_out));
-    if (vp.method == VPPX_METHOD_RND)
-        VPPX_HIP(hipMemcpyAsync(s.h_out + fs->o_draws, s.d_out + fs->o_draws, (size_t)8 * nb, hipMemcpyDeviceToHost, fs->s_out));
-    VPPX_HIP(hipEventRecord(s.ev_out, fs->s_out));
+    s.out_method_rnd = vp.method == VPPX_METHOD_RND;
+    s.out_pending = true;
+    // Copy-outs ride in the NEXT batch, behind its aggregation: the lock-step launch goes at the pace of its slowest CU, and a CU
+    // that also hosts copy-out waves (stores over PCIe back up its memory pipeline) is slow -- next to the copy-out the launch took
+    // 2.2 ms instead of 1.65.  The sum / WTA kernel that follows hands out blocks as CUs come free and loses only what the copy-out
+    // takes.  So: what earlier batches still owe is enqueued now, behind this call's aggregation event; this batch's own copy-out
+    // waits for the next submit -- or for the pop / flush / re-run that needs it first (fs_copy_out_now).  With two slots the host
+    // would sit out half a batch waiting for results that are held back: a ring of two copies out at once, as it always did.
+    for (auto &o : fs->slots)
+        if (o.out_pending && (&o != &s || fs->depth < 3)) {
+            const int rc2 = fs_copy_out(fs, o, &o != &s && ctx->have_agg_done);
+            if (rc2) return rc2;
+        }
     s.submitted = true;
     s.verified = false;
     return 0;
@@ -299,6 +366,10 @@ extern "C" int vppx_fstream_counts(vppx_fstream *fs, int64_t *pushed, int64_t *f
 static int fs_verify(vppx_fstream *fs, Slot &head)
 {
     vppx_ctx *ctx = fs->ctx;
+    if (head.out_pending) { // no later batch has been submitted: nothing to hide behind
+        const int rc = fs_copy_out(fs, head, false);
+        if (rc) return rc;
+    }
     VPPX_HIP(hipEventSynchronize(head.ev_out));
     if (vppx_lockstep_check_internal(ctx) == 0 && !fs->lost_pending) {
         head.verified = true;
@@ -317,6 +388,11 @@ static int fs_verify(vppx_fstream *fs, Slot &head)
             if (rc) return rc;
             fs->reruns++;
         }
+        for (auto &o : fs->slots)
+            if (o.out_pending) {
+                const int rc = fs_copy_out(fs, o, false);
+                if (rc) return rc;
+            }
         VPPX_HIP(hipStreamSynchronize(fs->s_out));
         if (vppx_lockstep_check_internal(ctx) == 0 && !fs->lost_pending) {
             for (uint64_t b = fs->pop_batch; b < fs->sub_batches; b++) fs->slots[b % fs->depth].verified = true;

@@ -87,7 +87,8 @@ class FrameStream:
     """The hot path for a caller that holds ONE numpy frame at a time (test.py:291-311: a DataLoader with batch size 1, then
     :154-225 per frame) at the rate of the batched kernels: frames go in one at a time, results come out one at a time in
     input order, and in between the library batches them (libvppx `vppx_fstream_*`: one multi-threaded copy into a page-locked
-    ring, upload of batch k+1 under batch k's kernels, download under batch k+1's).
+    ring of `depth` batches, upload of batch k+1 under batch k's kernels, copy-out under batch k+1's sum / WTA kernel; depth 3 is
+    what keeps the device busy, depth 2 saves a third of the ring's page-locked and device memory at ~10 % of the rate).
 
         with FrameStream(540, 960, maskocc=True, rsgm_kw=dict(dmax=192), seed=7) as fs:
             for disp in fs.run((l, r, hints) for l, r, hints in loader):     # input order
@@ -102,7 +103,7 @@ class FrameStream:
     Results: the float32 disparity map, or with return_patterns (disparity, left_vpp, right_vpp, conf_map or None); each a fresh
     array.  `draws` of the last popped frame (rand() calls it consumed) is in `last_draws`."""
 
-    def __init__(self, height, width, channels=3, batch=None, depth=2, seed=1, maskocc=False, with_g_occ=False, occ_kw=None,
+    def __init__(self, height, width, channels=3, batch=None, depth=3, seed=1, maskocc=False, with_g_occ=False, occ_kw=None,
                  vpp_kw=None, rsgm_kw=None, return_patterns=False, copy_threads=-1, device=-1):
         vk = dict(vpp_kw or {})
         method = vk.pop("method", "rnd")
