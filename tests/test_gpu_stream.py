@@ -143,7 +143,8 @@ def test_stream_refuses_what_it_cannot_do_and_reports_a_full_ring():
         assert got.value == 0
 
 
-def test_stream_reruns_batches_after_a_lost_lock_step():
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_stream_reruns_batches_after_a_lost_lock_step(depth):
     """VPPX_V3_SPIN_LIMIT=1 makes the fused aggregation give up at the first neighbour record that is not there yet: the stream
     notices at the pop, re-runs what was in flight on the line-parallel layout, and hands out the right disparities."""
     from vppstereo_amd.pipeline import FrameStream
@@ -154,7 +155,7 @@ def test_stream_reruns_batches_after_a_lost_lock_step():
     old = {k: os.environ.get(k) for k in ("VPPX_VERT", "VPPX_V3_SPIN_LIMIT")}
     os.environ["VPPX_VERT"], os.environ["VPPX_V3_SPIN_LIMIT"] = "3", "1"
     try:
-        fs = FrameStream(H, W, batch=8, seed=9, rsgm_kw=dict(dmax=D))
+        fs = FrameStream(H, W, batch=8, depth=depth, seed=9, rsgm_kw=dict(dmax=D))   # (ring of 3+: some copy-outs are still held back at the re-run)
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
