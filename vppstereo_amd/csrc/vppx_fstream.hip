@@ -191,11 +191,12 @@ extern "C" int vppx_fstream_create(vppx_ctx *ctx, const VppxOccParams *op, const
 extern "C" void vppx_fstream_destroy(vppx_fstream *fs) { fs_free(fs); }
 
 // Results leave the device through a kernel of a few workgroups that stores into the pinned ring (FS_COPY_WGS x 256 lanes, 16 bytes
-// each per trip: ~20 GB/s, a batch in ~2 ms of the ~4 ms the next batch computes).  Why not hipMemcpyAsync: which engine a device ->
-// pinned-host copy takes is the runtime's choice -- SDMA with ROCm 7.2's libamdhip64, a 256-workgroup blit kernel with the 7.0 one a
-// process that imported torch has loaded -- and the blit kernel, saturating PCIe from every CU, stretched whatever front-stage kernel
-// of the next batch ran beside it (pad+gray+census 66 -> 620 us, the batch period 4.1 -> 4.7 ms; tools/d2h_probe.hip,
-// docs/NOTEBOOK.md round 6).  A trickle of few waves keeps few PCIe writes in flight and leaves the CUs to the hot path.
+// each per trip: a 41 MB batch in 0.7-1.0 ms alone, ~1.4 ms beside the sum / WTA kernel, of the ~4 ms the next batch computes).
+// Why not hipMemcpyAsync: which engine a device -> pinned-host copy takes is the runtime's choice -- SDMA with ROCm 7.2's
+// libamdhip64, a 256-workgroup blit kernel with the 7.0 one a process that imported torch has loaded -- and the blit kernel,
+// saturating PCIe from every CU, stretched whatever front-stage kernel of the next batch ran beside it (pad+gray+census 66 -> 620 us,
+// the batch period 4.1 -> 4.7 ms; tools/d2h_probe.hip, docs/NOTEBOOK.md round 6).  Few waves keep few PCIe writes in flight and
+// leave the CUs to the hot path; 4, 8 and 16 workgroups, or the same lanes as one-wave workgroups on more CUs, measure alike.
 #ifndef FS_COPY_WGS
 #define FS_COPY_WGS 8
 #endif
@@ -286,10 +287,10 @@ static int fs_submit(vppx_fstream *fs, Slot &s, bool upload)
     s.out_pending = true;
     // Copy-outs ride in the NEXT batch, behind its aggregation: the lock-step launch goes at the pace of its slowest CU, and a CU
     // that also hosts copy-out waves (stores over PCIe back up its memory pipeline) is slow -- next to the copy-out the launch took
-    // 2.2 ms instead of 1.65.  The sum / WTA kernel that follows hands out blocks as CUs come free and loses only what the copy-out
-    // takes.  So: what earlier batches still owe is enqueued now, behind this call's aggregation event; this batch's own copy-out
-    // waits for the next submit -- or for the pop / flush / re-run that needs it first (fs_copy_out_now).  With two slots the host
-    // would sit out half a batch waiting for results that are held back: a ring of two copies out at once, as it always did.
+    // 2.2 ms instead of 1.65; the sum / WTA kernel beside it pays less (1.22 -> 1.5 ms).  So: what earlier batches still owe is
+    // enqueued now, behind this call's aggregation event; this batch's own copy-out waits for the next submit -- or for the pop or
+    // re-run that needs it first (fs_verify).  With two slots the host would sit out half a batch waiting for results that are held
+    // back: a ring of two copies out at once.
     for (auto &o : fs->slots)
         if (o.out_pending && (&o != &s || fs->depth < 3)) {
             const int rc2 = fs_copy_out(fs, o, &o != &s && ctx->have_agg_done);
