@@ -267,20 +267,32 @@ static int fs_submit(vppx_fstream *fs, Slot &s, bool upload)
     // the hot path reports an earlier call's lost lock step instead of running (its caller could not tell otherwise): a stream
     // looks first, keeps going -- the context now rests on the line-parallel layout -- and re-runs what was in flight at the next pop
     if (vppx_lockstep_check_internal(ctx) != 0) fs->lost_pending = true;
-    int rc = vppx_inputs_ready_event(ctx, (void *)s.ev_in);
-    if (rc) return rc;
-    ctx->draws_dst = (vp.method == VPPX_METHOD_RND) ? (unsigned long long *)(s.d_out + fs->o_draws) : nullptr;
     u8 *lv = (fs->flags & VPPX_FS_PATTERNS) ? s.d_out + fs->o_lv : nullptr;
     u8 *rv = (fs->flags & VPPX_FS_PATTERNS) ? s.d_out + fs->o_rv : nullptr;
-    if (fs->have_op)
-        rc = vppx_occ_vpp_rsgm_dev(ctx, &fs->op, &vp, &fs->rp, nb, fs->H, fs->W, fs->C, s.d_in + fs->o_left, s.d_in + fs->o_right,
-                                   (const float *)(s.d_in + fs->o_hint), (fs->flags & VPPX_FS_MASK) ? s.d_out + fs->o_conf : nullptr, lv, rv,
+    int rc = 0;
+    for (int attempt = 0;; attempt++) {
+        const long lost_before = ctx->lockstep_failures;
+        rc = vppx_inputs_ready_event(ctx, (void *)s.ev_in);
+        if (rc) return rc;
+        ctx->draws_dst = (vp.method == VPPX_METHOD_RND) ? (unsigned long long *)(s.d_out + fs->o_draws) : nullptr;
+        if (fs->have_op)
+            rc = vppx_occ_vpp_rsgm_dev(ctx, &fs->op, &vp, &fs->rp, nb, fs->H, fs->W, fs->C, s.d_in + fs->o_left, s.d_in + fs->o_right,
+                                       (const float *)(s.d_in + fs->o_hint), (fs->flags & VPPX_FS_MASK) ? s.d_out + fs->o_conf : nullptr, lv, rv,
+                                       (float *)(s.d_out + fs->o_disp));
+        else
+            rc = vppx_vpp_rsgm_dev(ctx, &vp, &fs->rp, nb, fs->H, fs->W, fs->C, s.d_in + fs->o_left, s.d_in + fs->o_right,
+                                   (const float *)(s.d_in + fs->o_hint), (fs->flags & VPPX_FS_GOCC) ? s.d_in + fs->o_gocc : nullptr, lv, rv,
                                    (float *)(s.d_out + fs->o_disp));
-    else
-        rc = vppx_vpp_rsgm_dev(ctx, &vp, &fs->rp, nb, fs->H, fs->W, fs->C, s.d_in + fs->o_left, s.d_in + fs->o_right,
-                               (const float *)(s.d_in + fs->o_hint), (fs->flags & VPPX_FS_GOCC) ? s.d_in + fs->o_gocc : nullptr, lv, rv,
-                               (float *)(s.d_out + fs->o_disp));
-    ctx->draws_dst = nullptr;
+        ctx->draws_dst = nullptr;
+        // A launch still in flight can lose its lock step between the look above and the hot path's own look, just before it queues
+        // the aggregation (the deeper the ring, the more launches are in flight): the call then reports that instead of running.
+        // Same treatment: note it, run the call again (each look consumes one report; at most `depth` launches are in flight).
+        if (rc != 0 && ctx->lockstep_failures != lost_before && attempt < fs->depth) {
+            fs->lost_pending = true;
+            continue;
+        }
+        break;
+    }
     if (rc) return rc;
     VPPX_HIP(hipEventRecord(s.ev_done, ctx->stream));
     s.out_method_rnd = vp.method == VPPX_METHOD_RND;
